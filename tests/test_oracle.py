@@ -1,0 +1,187 @@
+"""Pin the CPU oracle (oracle/turtle_oracle.c): against the committed golden
+vectors produced from the reference (always), and bit-for-bit against the
+reference TU compiled in place (oracle/_ref) where that library exists."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _checkers import Params, bins_digest
+from steganosaurus_amd.synth import cover_rgb, gradient_cover, secret_ascii, n_stream_bits
+
+VARIANTS = {
+    "default": dict(),
+    "jitter": dict(jitter=0.05),
+    "adaptive": dict(adaptive_alpha=1),
+    "center": dict(center=1),
+    "alpha_density": dict(alpha=0.3, density=0.5, rmin=0.1, rmax=0.6),
+}
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with open(os.path.join(golden_dir, "kat.json")) as f:
+        return json.load(f)
+
+
+def test_keys_and_keystream(orc, kat):
+    pk = hashlib.sha256(kat["pass"].encode()).digest()
+    assert orc.sha256(kat["pass"].encode()) == pk == bytes.fromhex(kat["path_key"])
+    kw, kr, kg, kb = orc.subkeys(pk)
+    assert (kw.hex(), kr.hex(), kg.hex(), kb.hex()) == (kat["key_walk"], kat["key_r"], kat["key_g"], kat["key_b"])
+    assert orc.ks_bytes(kw, 64).tobytes().hex() == kat["ks_walk_first64"]
+    assert orc.ks_opcodes(kw, 64).tolist() == kat["opcodes_first64"]
+    # survey KATs
+    assert kat["ks_walk_first64"].startswith("bc4cea4c83af5360aaf835b424456d9a")
+    assert kat["opcodes_first64"][:12] == [5, 7, 0, 4, 6, 3, 5, 2, 2, 3, 1, 0]
+
+
+def test_walk_golden(orc, kat):
+    kw = bytes.fromhex(kat["key_walk"])
+    for w in kat["walks"]:
+        if w["PH"] * w["PW"] > 2048 * 2048 or w["n"] > 100000:
+            continue  # big ones: test_walk_golden_large
+        rc, bins, sk, ctr, start = orc.walk(kw, w["PH"], w["PW"], w["n"], w.get("rmin", 0.05), w.get("rmax", 0.45),
+                                            w.get("density", 0.7))
+        assert rc == 0
+        assert start.tolist() == w["start"] and bins[:8].tolist() == w["first8"]
+        assert (sk, ctr) == (w["skipped"], w["ks_ctr"])
+        assert bins_digest(bins) == w["sha256"], (w["PH"], w["PW"])
+
+
+def test_walk_golden_large(orc, kat):
+    kw = bytes.fromhex(kat["key_walk"])
+    big = [w for w in kat["walks"] if w["PH"] * w["PW"] > 2048 * 2048 or w["n"] > 100000]
+    assert len(big) >= 3
+    for w in big:
+        rc, bins, sk, ctr, start = orc.walk(kw, w["PH"], w["PW"], w["n"])
+        assert rc == 0 and bins_digest(bins) == w["sha256"] and (sk, ctr) == (w["skipped"], w["ks_ctr"])
+
+
+def test_walk_exhaustion_returns_error(orc, kat):
+    """The reference spins forever here; the restatement must bound it."""
+    kw = bytes.fromhex(kat["key_walk"])
+    rc, *_ = orc.walk(kw, 32, 32, 5000)
+    assert rc == -1
+    rc, *_ = orc.walk(kw, 32, 32, 10, density=1.0)   # (uint8_t)256 == 0: never hits
+    assert rc == -1
+
+
+def test_fft_sign_kat(orc, kat):
+    d = np.zeros((4, 8), np.complex128)
+    d[1, 1] = 1
+    F = orc.fft2d(d)
+    assert [F[0, 1].real, F[0, 1].imag] == kat["delta_4x8"]["F01"]
+    assert [F[1, 0].real, F[1, 0].imag] == kat["delta_4x8"]["F10"]
+    assert F[0, 1].imag > 0.7 and F[1, 0].imag == 1.0           # exp(+i...) forward, finding 3
+    back = orc.fft2d(F, inverse=True)
+    assert np.allclose(back, d, atol=1e-15)
+
+
+@pytest.mark.parametrize("wh", [(64, 64), (48, 40), (100, 30)])
+@pytest.mark.parametrize("center", [0, 1])
+def test_forward_golden(orc, golden_dir, wh, center):
+    g = np.load(os.path.join(golden_dir, f"fft_{wh[0]}x{wh[1]}_c{center}.npz"))
+    img = cover_rgb(wh[0], wh[1], int(g["cover_index"]))
+    spec, med = orc.forward_rgb8(img, center)
+    assert np.array_equal(spec, g["spec"])
+    assert np.array_equal(med, g["med"])
+    cap, _ = orc.capacity_rgb8(img, Params(center=center))
+    assert cap == int(g["capacity"])
+
+
+@pytest.mark.parametrize("name", ["lcg", "grad"])
+def test_forward_512_golden(orc, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"fft_512_{name}.npz"))
+    img = cover_rgb(512, 512, 0) if name == "lcg" else gradient_cover(512, 512, 1)
+    spec, med = orc.forward_rgb8(img)
+    pos = g["pos"]
+    for p in range(3):
+        assert np.array_equal(spec[p][pos[p, :, 0], pos[p, :, 1]], g["vals"][p])
+    assert np.array_equal(med, g["med"])
+    assert np.array_equal(spec[:, :, 0], g["col0"]) and np.array_equal(spec[:, 0, :], g["row0"])
+    cap, _ = orc.capacity_rgb8(img)
+    assert cap == int(g["capacity"])
+
+
+@pytest.mark.parametrize("wh", [(64, 64), (48, 40), (256, 256)])
+def test_embed_extract_golden(orc, golden_dir, wh, kat):
+    g = np.load(os.path.join(golden_dir, f"embed_{wh[0]}x{wh[1]}.npz"))
+    pk = bytes.fromhex(kat["path_key"])
+    img = cover_rgb(wh[0], wh[1], 0)
+    bits = g["bits"]
+    for vname, kw in VARIANTS.items():
+        P = Params(**kw)
+        stego, spec, bins = orc.embed_rgb8(img, pk, bits, P, want_spec=True, want_bins=True)
+        assert np.array_equal(bins, g[f"{vname}_bins"]), vname
+        assert np.array_equal(stego, g[f"{vname}_stego"]), vname
+        if f"{vname}_spec" in g:
+            assert np.array_equal(spec, g[f"{vname}_spec"]), vname
+        raw = orc.extract_bits(g[f"{vname}_stego"], pk, len(bits), P)
+        assert np.array_equal(raw, g[f"{vname}_raw"]), vname
+
+
+@pytest.mark.parametrize("name", ["lcg", "grad"])
+def test_config1_golden(orc, golden_dir, name, kat):
+    """BASELINE.json configs[0]: 512x512, 1 KB secret, defaults."""
+    g = np.load(os.path.join(golden_dir, f"embed_512_{name}.npz"))
+    pk = bytes.fromhex(kat["path_key"])
+    img = cover_rgb(512, 512, 0) if name == "lcg" else gradient_cover(512, 512, 1)
+    n = int(g["n_bits"])
+    assert n == n_stream_bits(1024) == 59152
+    bits = np.unpackbits(g["bits"])[:n]
+    stego, _, bins = orc.embed_rgb8(img, pk, bits, Params(), want_bins=True)
+    assert bins_digest(bins) == str(g["bins_sha256"])
+    assert hashlib.sha256(stego.tobytes()).hexdigest() == str(g["stego_sha256"])
+    assert np.array_equal(stego.astype(np.int16) - img, g["stego_diff"])
+    raw = orc.extract_bits(stego, pk, n, Params())
+    assert np.array_equal(raw, np.unpackbits(g["raw"])[:n])
+
+
+@pytest.mark.parametrize("wh", [(600, 400), (300, 500)])
+def test_nonpow2_golden(orc, golden_dir, wh, kat):
+    """Non-power-of-two images: the reference cannot round-trip them (finding 1);
+    parity = identical *erroneous* raw bit vector."""
+    g = np.load(os.path.join(golden_dir, f"nonpow2_{wh[0]}x{wh[1]}.npz"))
+    pk = bytes.fromhex(kat["path_key"])
+    img = cover_rgb(wh[0], wh[1], 0)
+    n = int(g["n_bits"])
+    bits = np.unpackbits(g["bits"])[:n]
+    stego, _, bins = orc.embed_rgb8(img, pk, bits, Params(), want_bins=True)
+    assert bins_digest(bins) == str(g["bins_sha256"])
+    assert np.array_equal(stego.astype(np.int16) - img, g["stego_diff"])
+    raw = orc.extract_bits(stego, pk, n, Params())
+    assert np.array_equal(raw, np.unpackbits(g["raw"])[:n])
+    assert 0.2 < (raw != bits).mean() < 0.45
+
+
+# ------------------------------------------------------------------ live reference (container only)
+def test_against_live_reference(orc, ref):
+    rng = np.random.default_rng(11)
+    pk = hashlib.sha256(b"another pass").digest()
+    assert orc.subkeys(pk) == ref.subkeys(pk)
+    kw = orc.subkeys(pk)[0]
+    assert np.array_equal(orc.ks_bytes(kw, 5000), ref.ks_bytes(kw, 5000))
+    for n in (2, 8, 128, 1024):
+        a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        assert np.array_equal(orc.fft1d(a), ref.fft1d(a))
+        assert np.array_equal(orc.fft1d(a, True), ref.fft1d(a, True))
+    for (W, H) in [(33, 17), (128, 64), (200, 120)]:
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        so, mo = orc.forward_rgb8(img)
+        sr, mr = ref.forward_rgb8(img)
+        assert np.array_equal(so, sr) and np.array_equal(mo, mr)
+        PH, PW = orc.next_pow2(H), orc.next_pow2(W)
+        a = orc.walk(kw, PH, PW, 150)
+        b = ref.walk(kw, PH, PW, 150)
+        assert np.array_equal(a[1], b[1]) and a[2:4] == b[2:4] and np.array_equal(a[4], b[4])
+        bits = rng.integers(0, 2, 150).astype(np.uint8)
+        for kwargs in VARIANTS.values():
+            P = Params(**kwargs)
+            eo = orc.embed_rgb8(img, pk, bits, P, True, True)
+            er = ref.embed_rgb8(img, pk, bits, P, True, True)
+            assert all(np.array_equal(x, y) for x, y in zip(eo, er))
+            assert np.array_equal(orc.extract_bits(eo[0], pk, 150, P), ref.extract_bits(er[0], pk, 150, P))
+        assert orc.capacity_rgb8(img)[0] == ref.capacity_rgb8(img)[0]
