@@ -1,0 +1,171 @@
+/* turtlefft_hip.h -- C ABI of libturtlefft_hip.so, the MI355X (gfx950) replacement
+ * for the 2-D-FFT phase-embedding hot path of rickenator/steganosaurus.
+ *
+ * The reference has no FFI layer: the path is reachable only through the
+ * file-static functions of steganosaurus/src/steganosaur.cpp (cited S:<line>).
+ * Each entry point below names the reference lines it replaces; INTEGRATION.md
+ * shows the patch a maintainer of the reference would apply to do_embed /
+ * do_extract to bind them.
+ *
+ * Conventions
+ *   - every function returns TFFT_OK (0) or a negative tfft_status; nothing
+ *     calls exit() and nothing throws across the boundary;
+ *   - a context owns all device memory, its HIP stream(s) and twiddle tables;
+ *     one context is used from one host thread at a time, distinct contexts
+ *     (also on distinct devices) may be used concurrently;
+ *   - "slot" = one resident image: its three half-spectra stay in HBM between
+ *     calls (forward -> medians/capacity -> embed/read -> inverse), exactly the
+ *     lifetime of FR/FG/FB/F3 in the reference (S:917-1100);
+ *   - pointers are HOST pointers unless the function name ends in _dev, in
+ *     which case they are device pointers valid on the context's device;
+ *   - transforms use the reference's sign convention: forward kernel
+ *     exp(+2*pi*i*nk/N) (S:347), inverse exp(-...) scaled 1/N per dimension
+ *     (S:357); images are zero-padded to next_pow2 in each dimension (S:393-398)
+ *     and the inverse crops back to W x H (S:399-403);
+ *   - there is no CPU fallback: without a usable gfx950 device tfft_create
+ *     fails with TFFT_E_NO_DEVICE.
+ */
+#ifndef TURTLEFFT_HIP_H
+#define TURTLEFFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFFT_ABI_VERSION 1
+
+typedef enum tfft_status {
+    TFFT_OK = 0,
+    TFFT_E_INVALID = -1,      /* bad argument (null pointer, slot out of range, size 0 ...) */
+    TFFT_E_NO_DEVICE = -2,    /* no HIP device / not gfx950 / HIP runtime error at create */
+    TFFT_E_TOO_LARGE = -3,    /* image larger than the context was created for, or > TFFT_MAX_DIM */
+    TFFT_E_NOMEM = -4,        /* host or device allocation failed */
+    TFFT_E_HIP = -5,          /* HIP runtime error during a launch/copy (see tfft_last_hip_error) */
+    TFFT_E_STATE = -6,        /* slot holds no forward spectrum yet */
+    TFFT_E_EXHAUSTED = -7,    /* walk: annulus exhausted (the reference would spin forever) */
+    TFFT_E_BIN_RANGE = -8     /* a bin lies outside the padded grid or on an excluded axis */
+} tfft_status;
+
+#define TFFT_MAX_DIM 16384     /* largest padded width/height handled (rows of PW/2 complex fit in LDS) */
+
+typedef struct tfft_ctx tfft_ctx;
+typedef struct tfft_walk tfft_walk;
+
+/* One embedding position, as produced by Turtle::advance_to_valid (S:778-804):
+ * colour plane 0..2 and UN-shifted frequency indices on the padded grid. */
+typedef struct tfft_bin {
+    uint16_t x;        /* 0 .. PW-1 */
+    uint16_t y;        /* 0 .. PH-1 */
+    uint8_t plane;     /* 0=R 1=G 2=B */
+    uint8_t rsv[3];    /* must be 0 */
+} tfft_bin;
+
+/* ------------------------------------------------------------------ context */
+int tfft_abi_version(void);
+const char* tfft_strerror(int status);
+
+/* Allocates `n_slots` resident images of up to max_w x max_h pixels on HIP
+ * device `device`.  Replaces the vectors of S:912-917 / S:1015. */
+int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out);
+int tfft_destroy(tfft_ctx* ctx);
+/* Run all work of this context on an existing HIP stream (e.g. the framework's
+ * current stream) instead of the context's own.  stream = hipStream_t. */
+int tfft_set_stream(tfft_ctx* ctx, void* hip_stream);
+int tfft_sync(tfft_ctx* ctx);
+int tfft_last_hip_error(const tfft_ctx* ctx);
+size_t tfft_device_bytes(const tfft_ctx* ctx);
+
+/* ------------------------------------------------------------- forward side
+ * to_planes_u8 + apply_center + pad_to_fft + fft2d(forward) x3  (S:912-921,
+ * S:1116-1123).  rgb = H*W*3 interleaved bytes.  Returns the padded size. */
+int tfft_forward_rgb8(tfft_ctx* ctx, int slot, const uint8_t* rgb, int w, int h, int center, int* pw, int* ph);
+int tfft_forward_rgb8_dev(tfft_ctx* ctx, int slot, const void* rgb_dev, int w, int h, int center, int* pw, int* ph);
+
+/* median_abs x3 (S:922, S:404-409): element at sorted index P/2 of |F| over
+ * the FULL padded plane (mirror bins counted).  Synchronises. */
+int tfft_medians(tfft_ctx* ctx, int slot, double med[3]);
+
+/* count_plane (S:998-1008): sum over planes of floor(c/2), c = bins in the
+ * annulus [rmin,rmax]*min(PH,PW), off the axes, |F| >= thr[plane].  Synchronises. */
+int tfft_capacity(tfft_ctx* ctx, int slot, double rmin, double rmax, const double thr[3], uint64_t* usable);
+
+/* compute_cover_hash's magnitudes (S:428-436): |F[y][x]| for y,x < region of
+ * each plane, out = 3*region*region doubles.  Synchronises. */
+int tfft_lowfreq_mag(tfft_ctx* ctx, int slot, int region, double* out);
+
+/* ------------------------------------------------------------- embed / read
+ * The embed loop body, write_bit_on_bin (S:712-732), over a materialised bin
+ * list: F[y][x] = polar(max(1e-12,|F|), (bit ? +a : -a) + jitter[i]) and the
+ * Hermitian mirror = conj.  a = alpha, or alpha*clamp(|F|/med[plane],0.5,2)
+ * when `adaptive` (S:704-710).  jitter may be NULL (all zero).  Bins of one
+ * list must be distinct with distinct mirrors (the walk guarantees it). */
+int tfft_embed_bins(tfft_ctx* ctx, int slot, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
+                    uint64_t n, double alpha, int adaptive, const double med[3]);
+int tfft_embed_bins_dev(tfft_ctx* ctx, int slot, const void* bins_dev, const void* bits_dev, const void* jitter_dev,
+                        uint64_t n, double alpha, int adaptive, const double med[3]);
+
+/* read_bit_from_bin (S:734-746) over a bin list: bits_out[i] in {0,1}.  May be
+ * called repeatedly on a resident spectrum (912 header bits, then the payload:
+ * S:1223-1264).  The host variant synchronises. */
+int tfft_read_bins(tfft_ctx* ctx, int slot, const tfft_bin* bins, const float* jitter, uint64_t n, double alpha,
+                   int adaptive, const double med[3], uint8_t* bits_out);
+int tfft_read_bins_dev(tfft_ctx* ctx, int slot, const void* bins_dev, const void* jitter_dev, uint64_t n,
+                       double alpha, int adaptive, const double med[3], void* bits_out_dev);
+
+/* ------------------------------------------------------------- inverse side
+ * fft2d(inverse) x3 + ifft_crop + apply_center + from_planes_u8 (S:1100-1103):
+ * real part, round half away from zero, clamp to 0..255, interleave.  The
+ * slot's spectrum is consumed.  The host variant synchronises. */
+int tfft_inverse_rgb8(tfft_ctx* ctx, int slot, uint8_t* rgb_out);
+int tfft_inverse_rgb8_dev(tfft_ctx* ctx, int slot, void* rgb_out_dev);
+
+/* Parity/debug export: the FULL padded spectra, 3*PH*PW interleaved (re,im)
+ * floats, mirror half reconstructed by Hermitian symmetry.  Synchronises. */
+int tfft_download_spectrum(tfft_ctx* ctx, int slot, float* out);
+
+/* ------------------------------------------------------------------ batches
+ * n independent images of identical size sharing ONE bin list (the walk does
+ * not depend on image content: S:797-799).  Images are pipelined over the
+ * context's slots, one HIP stream per slot.  All pointers are device pointers;
+ * image i is at rgb + i*w*h*3, its bits at bits + i*n_bits.
+ *   embed  : forward -> [medians+capacity when usable_out != NULL] -> embed -> inverse
+ *   extract: forward -> read
+ * usable_out (device, n uint64) receives each image's capacity so the caller
+ * can raise "Message too large" (S:1009-1012) without a sync per image. */
+int tfft_embed_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
+                         const void* bins_dev, const void* bits_dev, uint64_t n_bits, double alpha,
+                         double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev);
+int tfft_extract_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
+                           const void* bins_dev, uint64_t n_bits, double alpha, void* bits_out_dev);
+
+/* --------------------------------------------------------- keyed walk (HOST)
+ * KS + Turtle + the density gate (S:665-695, S:749-810, S:1076-1081): a
+ * resumable generator of embedding positions.  Pure host code, no device.
+ * key_walk = first 32 bytes of HKDF-Expand(path_key, "turtle_keys") (S:1054-1058).
+ * tfft_walk_next appends the next n positions; *skipped (optional) is
+ * incremented by the density-rejected bins.  Returns TFFT_E_EXHAUSTED instead
+ * of spinning when no acceptable bin is left. */
+int tfft_walk_create(const uint8_t key_walk[32], int ph, int pw, double rmin, double rmax, double density,
+                     tfft_walk** out);
+int tfft_walk_next(tfft_walk* w, uint64_t n, tfft_bin* out, uint64_t* skipped);
+int tfft_walk_start(const tfft_walk* w, int* plane, int* y, int* x);
+uint32_t tfft_walk_ks_blocks(const tfft_walk* w);
+int tfft_walk_destroy(tfft_walk* w);
+/* KS::jitter (S:690-694) for a materialised list: out[i] = jitter drawn from
+ * the plane's own keystream (keys_rgb = 3*32 bytes key_r|key_g|key_b) in list
+ * order; two bytes are consumed per bin even when max_jitter == 0 (S:719). */
+int tfft_walk_jitter(const uint8_t keys_rgb[96], const tfft_bin* bins, uint64_t n, double max_jitter, float* out);
+
+/* ------------------------------------------------------------ measurement
+ * Device-side timing of whatever was enqueued between the two calls on the
+ * context's stream (hipEvent pair on that stream). */
+int tfft_timer_begin(tfft_ctx* ctx);
+int tfft_timer_end(tfft_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TURTLEFFT_HIP_H */

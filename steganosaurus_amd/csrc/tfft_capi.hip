@@ -1,0 +1,558 @@
+// tfft_capi.hip -- context management and the C ABI of libturtlefft_hip.so
+// (include/turtlefft_hip.h).  Host C++ only; all device work is in
+// tfft_kernels.hip.  There is deliberately no CPU fallback in this file: every
+// entry point that computes needs a live gfx950 context.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <new>
+#include <vector>
+
+#include "tfft_kernels.h"
+
+extern "C" void tfft_internal_radius_bounds(double lo, double hi, uint64_t* s_lo, uint64_t* s_hi, int* empty);
+
+namespace {
+
+using namespace tfft;
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }        // S:369
+int ilog2i(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+struct Slot {
+    uint8_t* img = nullptr;        // W*H*3 staging (host-pointer API) / output
+    float2* spec = nullptr;        // [3][PH][M]
+    float2* tmp = nullptr;         // [3][PH][M]
+    SelectState* sel = nullptr;    // [3]
+    float* med = nullptr;          // [3] medians of |F| (float bit-exact order statistic)
+    unsigned long long* counts = nullptr;   // [3] capacity counters
+    unsigned long long* usable = nullptr;   // [1]
+    int* err = nullptr;            // [1] sticky bin-range flag
+    hipStream_t stream = nullptr;  // pipeline stream of this slot (batch API)
+    hipEvent_t done = nullptr;
+    int W = 0, H = 0, PW = 0, PH = 0, PWi = 0, center = 0;
+    bool has_spec = false;
+};
+
+struct ColPlan { bool direct; int log_n1, log_n2; };
+
+}  // namespace
+
+struct tfft_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, n_slots = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_fork = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    int last_hip = 0;
+    size_t dev_bytes = 0;
+    std::vector<Slot> slots;
+    std::map<int, float2*> tw;           // N -> table exp(+2 pi i j/N), j < N
+    // staging for the host-pointer embed/read API
+    void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
+    size_t stage_cap = 0;
+    int cols_direct_max_log = 9;         // PH <= 512: one column pass; taller: two-step N1 x N2
+    int cols_force_log_n1 = -1;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                  \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) { (ctx)->last_hip = (int)e_; return TFFT_E_HIP; } \
+    } while (0)
+
+int dev_alloc(tfft_ctx* c, void** p, size_t bytes) {
+    if (hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; return TFFT_E_NOMEM; }
+    c->dev_bytes += bytes;
+    return TFFT_OK;
+}
+
+int get_twiddles(tfft_ctx* c, int n, const float2** out) {
+    auto it = c->tw.find(n);
+    if (it != c->tw.end()) { *out = it->second; return TFFT_OK; }
+    std::vector<float2> h((size_t)n);
+    for (int j = 0; j < n; j++) {
+        const double a = 2.0 * M_PI * (double)j / (double)n;
+        h[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    float2* d = nullptr;
+    int rc = dev_alloc(c, (void**)&d, sizeof(float2) * (size_t)n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    c->tw[n] = d;
+    *out = d;
+    return TFFT_OK;
+}
+
+ColPlan plan_cols(const tfft_ctx* c, int PH) {
+    const int l = ilog2i(PH);
+    ColPlan p;
+    if (l <= c->cols_direct_max_log && c->cols_force_log_n1 < 0) { p.direct = true; p.log_n1 = 0; p.log_n2 = l; return p; }
+    p.direct = false;
+    int l1 = (c->cols_force_log_n1 >= 0) ? c->cols_force_log_n1 : l / 2;
+    if (l1 < 1) l1 = 1;
+    if (l1 > l - 1) l1 = l - 1;
+    if (l - l1 > 10) l1 = l - 10;
+    p.log_n1 = l1; p.log_n2 = l - l1;
+    return p;
+}
+
+int set_geometry(tfft_ctx* c, Slot& s, int w, int h, int center) {
+    if (w < 1 || h < 1) return TFFT_E_INVALID;
+    if (w > c->max_w || h > c->max_h) return TFFT_E_TOO_LARGE;
+    s.W = w; s.H = h; s.PW = next_pow2(w); s.PH = next_pow2(h);
+    s.PWi = s.PW < 2 ? 2 : s.PW;          // the real<->half-complex row transform needs an even length
+    s.center = center ? 1 : 0;
+    if (s.PWi > TFFT_MAX_DIM || s.PH > TFFT_MAX_DIM) return TFFT_E_TOO_LARGE;
+    return TFFT_OK;
+}
+
+// forward: rows (u8 -> tmp) then columns (tmp -> spec)
+int enqueue_forward(tfft_ctx* c, Slot& s, const uint8_t* rgb_dev, hipStream_t st) {
+    const int M = s.PWi / 2;
+    const float2 *tw_w, *tw_h;
+    int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
+    rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
+    RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f};
+    HIPCHK(c, launch_rows_fwd(rgb_dev, s.tmp, tw_w, rp, 1, st));
+    const ColPlan pl = plan_cols(c, s.PH);
+    ColParams cp{};
+    cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M;
+    if (pl.direct) {
+        cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
+        HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+    } else {
+        const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
+        // step 1: for every n2, length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
+        cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
+        HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, +1, 3, st));
+        // step 2: for every k1, length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
+        cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
+        HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+    }
+    s.has_spec = true;
+    return TFFT_OK;
+}
+
+// inverse: columns (spec -> tmp, only rows < H kept) then rows (tmp -> u8)
+int enqueue_inverse(tfft_ctx* c, Slot& s, uint8_t* rgb_out_dev, hipStream_t st) {
+    const int M = s.PWi / 2;
+    const float2 *tw_w, *tw_h;
+    int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
+    rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
+    const ColPlan pl = plan_cols(c, s.PH);
+    ColParams cp{};
+    cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M;
+    if (pl.direct) {
+        cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
+        HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+    } else {
+        const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
+        // step 1: for every k1, length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
+        cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
+        HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+        // step 2: for every n2, length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
+        cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
+        HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, -1, 3, st));
+    }
+    RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH))};
+    HIPCHK(c, launch_rows_inv(s.tmp, rgb_out_dev, tw_w, rp, 1, st));
+    s.has_spec = false;
+    return TFFT_OK;
+}
+
+EmbedParams embed_params(const Slot& s, uint64_t n, double alpha, int adaptive, const double med[3], bool has_jitter) {
+    EmbedParams p{};
+    p.n = n; p.PH = s.PH; p.PW = s.PW;
+    p.adaptive = adaptive ? 1 : 0;
+    p.generic = (adaptive || has_jitter || !(alpha > 0.0 && alpha < M_PI)) ? 1 : 0;
+    p.cos_a = (float)cos(alpha); p.sin_a = (float)sin(alpha);
+    p.alpha = alpha;
+    for (int i = 0; i < 3; i++) p.med[i] = med ? med[i] : 0.0;
+    return p;
+}
+
+CapParams cap_params(const Slot& s, double rmin, double rmax) {
+    CapParams p{};
+    p.PH = s.PH; p.PW = s.PW; p.PWi = s.PWi;
+    const int mn = s.PH < s.PW ? s.PH : s.PW;
+    const double lo = rmin * mn, hi = rmax * mn;        // S:1003
+    uint64_t a, b; int empty;
+    tfft_internal_radius_bounds(lo, hi, &a, &b, &empty);
+    p.s_lo = a; p.s_hi = b;
+    if (empty) { p.bw = p.bh = 0; return p; }
+    double lim = floor(hi) + 1.0;
+    p.bw = (int)(lim < (double)s.PW ? lim : (double)s.PW);
+    p.bh = (int)(lim < (double)s.PH ? lim : (double)s.PH);
+    return p;
+}
+
+int ensure_stage(tfft_ctx* c, uint64_t n) {
+    if (n <= c->stage_cap) return TFFT_OK;
+    hipStreamSynchronize(c->stream);
+    if (c->stage_bins) { hipFree(c->stage_bins); hipFree(c->stage_bits); hipFree(c->stage_jit); hipFree(c->stage_out); }
+    c->stage_bins = c->stage_bits = c->stage_jit = c->stage_out = nullptr; c->stage_cap = 0;
+    size_t cap = (size_t)n + (size_t)n / 4 + 1024;
+    if (dev_alloc(c, &c->stage_bins, cap * sizeof(tfft_bin)) || dev_alloc(c, &c->stage_bits, cap) ||
+        dev_alloc(c, &c->stage_jit, cap * sizeof(float)) || dev_alloc(c, &c->stage_out, cap))
+        return TFFT_E_NOMEM;
+    c->stage_cap = cap;
+    return TFFT_OK;
+}
+
+int check_err_flag(tfft_ctx* c, Slot& s) {
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, s.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag) {
+        HIPCHK(c, hipMemsetAsync(s.err, 0, sizeof(int), c->stream));
+        return TFFT_E_BIN_RANGE;
+    }
+    return TFFT_OK;
+}
+
+bool slot_ok(const tfft_ctx* c, int slot) { return c && slot >= 0 && slot < c->n_slots; }
+
+}  // namespace
+
+extern "C" {
+
+int tfft_abi_version(void) { return TFFT_ABI_VERSION; }
+
+const char* tfft_strerror(int status) {
+    switch (status) {
+        case TFFT_OK: return "ok";
+        case TFFT_E_INVALID: return "invalid argument";
+        case TFFT_E_NO_DEVICE: return "no usable gfx950 HIP device (this library has no CPU fallback)";
+        case TFFT_E_TOO_LARGE: return "image larger than the context allows";
+        case TFFT_E_NOMEM: return "out of memory";
+        case TFFT_E_HIP: return "HIP runtime error";
+        case TFFT_E_STATE: return "slot holds no forward spectrum";
+        case TFFT_E_EXHAUSTED: return "annulus exhausted";
+        case TFFT_E_BIN_RANGE: return "bin outside the grid or on an excluded axis";
+        default: return "unknown status";
+    }
+}
+
+int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
+    if (!out || max_w < 1 || max_h < 1 || n_slots < 1 || n_slots > 64) return TFFT_E_INVALID;
+    *out = nullptr;
+    int pw = next_pow2(max_w), ph = next_pow2(max_h);
+    if (pw < 2) pw = 2;
+    if (pw > TFFT_MAX_DIM || ph > TFFT_MAX_DIM) return TFFT_E_TOO_LARGE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TFFT_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return TFFT_E_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("TFFT_ALLOW_OTHER_ARCH")) return TFFT_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TFFT_E_NO_DEVICE;
+    tfft_ctx* c = new (std::nothrow) tfft_ctx();
+    if (!c) return TFFT_E_NOMEM;
+    c->device = device; c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots;
+    if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
+    if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
+    if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
+    int rc = TFFT_OK;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
+    c->own_stream = true;
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    hipEventCreate(&c->ev_t0); hipEventCreate(&c->ev_t1);
+    c->slots.resize(n_slots);
+    const size_t plane = (size_t)ph * (pw / 2) * sizeof(float2);
+    for (int i = 0; i < n_slots && rc == TFFT_OK; i++) {
+        Slot& s = c->slots[i];
+        rc = dev_alloc(c, (void**)&s.img, (size_t)max_w * max_h * 3 + 16);
+        if (!rc) rc = dev_alloc(c, (void**)&s.spec, 3 * plane);
+        if (!rc) rc = dev_alloc(c, (void**)&s.tmp, 3 * plane);
+        if (!rc) rc = dev_alloc(c, (void**)&s.sel, 3 * sizeof(SelectState));
+        if (!rc) rc = dev_alloc(c, (void**)&s.med, 4 * sizeof(float));
+        if (!rc) rc = dev_alloc(c, (void**)&s.counts, 4 * sizeof(unsigned long long));
+        if (!rc) rc = dev_alloc(c, (void**)&s.usable, sizeof(unsigned long long));
+        if (!rc) rc = dev_alloc(c, (void**)&s.err, sizeof(int));
+        if (!rc) {
+            hipMemset(s.counts, 0, 4 * sizeof(unsigned long long));
+            hipMemset(s.err, 0, sizeof(int));
+            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) rc = TFFT_E_HIP;
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        }
+    }
+    if (rc != TFFT_OK) { tfft_destroy(c); return rc; }
+    *out = c;
+    return TFFT_OK;
+}
+
+int tfft_destroy(tfft_ctx* c) {
+    if (!c) return TFFT_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (Slot& s : c->slots) {
+        hipFree(s.img); hipFree(s.spec); hipFree(s.tmp); hipFree(s.sel); hipFree(s.med); hipFree(s.counts);
+        hipFree(s.usable); hipFree(s.err);
+        if (s.stream) hipStreamDestroy(s.stream);
+        if (s.done) hipEventDestroy(s.done);
+    }
+    for (auto& kv : c->tw) hipFree(kv.second);
+    hipFree(c->stage_bins); hipFree(c->stage_bits); hipFree(c->stage_jit); hipFree(c->stage_out);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_t0) hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) hipEventDestroy(c->ev_t1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return TFFT_OK;
+}
+
+int tfft_set_stream(tfft_ctx* c, void* hip_stream) {
+    if (!c) return TFFT_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return TFFT_OK;
+}
+
+int tfft_sync(tfft_ctx* c) {
+    if (!c) return TFFT_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = TFFT_OK;
+    for (Slot& s : c->slots) {
+        int flag = 0;
+        HIPCHK(c, hipMemcpy(&flag, s.err, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag) { hipMemset(s.err, 0, sizeof(int)); rc = TFFT_E_BIN_RANGE; }
+    }
+    return rc;
+}
+
+int tfft_last_hip_error(const tfft_ctx* c) { return c ? c->last_hip : 0; }
+size_t tfft_device_bytes(const tfft_ctx* c) { return c ? c->dev_bytes : 0; }
+
+int tfft_forward_rgb8_dev(tfft_ctx* c, int slot, const void* rgb_dev, int w, int h, int center, int* pw, int* ph) {
+    if (!slot_ok(c, slot) || !rgb_dev) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    int rc = set_geometry(c, s, w, h, center);
+    if (rc) return rc;
+    if (pw) *pw = s.PW;
+    if (ph) *ph = s.PH;
+    return enqueue_forward(c, s, (const uint8_t*)rgb_dev, c->stream);
+}
+
+int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, int center, int* pw, int* ph) {
+    if (!slot_ok(c, slot) || !rgb) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    int rc = set_geometry(c, s, w, h, center);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(s.img, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice, c->stream));
+    if (pw) *pw = s.PW;
+    if (ph) *ph = s.PH;
+    return enqueue_forward(c, s, s.img, c->stream);
+}
+
+int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
+    if (!slot_ok(c, slot) || !med) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, c->stream));
+    float m[3];
+    HIPCHK(c, hipMemcpyAsync(m, s.med, sizeof m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) med[i] = (double)m[i];
+    return TFFT_OK;
+}
+
+int tfft_capacity(tfft_ctx* c, int slot, double rmin, double rmax, const double thr[3], uint64_t* usable) {
+    if (!slot_ok(c, slot) || !thr || !usable) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    CapParams p = cap_params(s, rmin, rmax);
+    for (int i = 0; i < 3; i++) p.thr[i] = thr[i];
+    HIPCHK(c, launch_capacity(s.spec, p, nullptr, s.counts, s.usable, c->stream));
+    unsigned long long u = 0;
+    HIPCHK(c, hipMemcpyAsync(&u, s.usable, sizeof u, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *usable = u;
+    return TFFT_OK;
+}
+
+int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
+    if (!slot_ok(c, slot) || !out || region < 1) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    if (region > s.PH || region > s.PW) return TFFT_E_INVALID;
+    const size_t bytes = (size_t)3 * region * region * sizeof(double);
+    if (bytes > (size_t)3 * s.PH * (s.PWi / 2) * sizeof(float2)) return TFFT_E_INVALID;
+    double* d = (double*)s.tmp;     // tmp is free between forward and inverse
+    HIPCHK(c, launch_lowfreq(s.spec, s.PH, s.PWi, region, d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TFFT_OK;
+}
+
+int tfft_embed_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* bits, const void* jitter, uint64_t n,
+                        double alpha, int adaptive, const double med[3]) {
+    if (!slot_ok(c, slot) || (n && (!bins || !bits)) || (adaptive && !med)) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    EmbedParams p = embed_params(s, n, alpha, adaptive, med, jitter != nullptr);
+    HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins, (const uint8_t*)bits, (const float*)jitter, p, s.err, c->stream));
+    return TFFT_OK;
+}
+
+int tfft_embed_bins(tfft_ctx* c, int slot, const tfft_bin* bins, const uint8_t* bits, const float* jitter, uint64_t n,
+                    double alpha, int adaptive, const double med[3]) {
+    if (!slot_ok(c, slot) || (n && (!bins || !bits))) return TFFT_E_INVALID;
+    if (!c->slots[slot].has_spec) return TFFT_E_STATE;
+    if (n == 0) return TFFT_OK;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage_bins, bins, n * sizeof(tfft_bin), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage_bits, bits, n, hipMemcpyHostToDevice, c->stream));
+    if (jitter) HIPCHK(c, hipMemcpyAsync(c->stage_jit, jitter, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = tfft_embed_bins_dev(c, slot, c->stage_bins, c->stage_bits, jitter ? c->stage_jit : nullptr, n, alpha, adaptive, med);
+    if (rc) return rc;
+    return check_err_flag(c, c->slots[slot]);
+}
+
+int tfft_read_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* jitter, uint64_t n, double alpha,
+                       int adaptive, const double med[3], void* bits_out) {
+    if (!slot_ok(c, slot) || (n && (!bins || !bits_out)) || (adaptive && !med)) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    EmbedParams p = embed_params(s, n, alpha, adaptive, med, jitter != nullptr);
+    HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins, (const float*)jitter, p, (uint8_t*)bits_out, s.err, c->stream));
+    return TFFT_OK;
+}
+
+int tfft_read_bins(tfft_ctx* c, int slot, const tfft_bin* bins, const float* jitter, uint64_t n, double alpha,
+                   int adaptive, const double med[3], uint8_t* bits_out) {
+    if (!slot_ok(c, slot) || (n && (!bins || !bits_out))) return TFFT_E_INVALID;
+    if (!c->slots[slot].has_spec) return TFFT_E_STATE;
+    if (n == 0) return TFFT_OK;
+    int rc = ensure_stage(c, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage_bins, bins, n * sizeof(tfft_bin), hipMemcpyHostToDevice, c->stream));
+    if (jitter) HIPCHK(c, hipMemcpyAsync(c->stage_jit, jitter, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = tfft_read_bins_dev(c, slot, c->stage_bins, jitter ? c->stage_jit : nullptr, n, alpha, adaptive, med, c->stage_out);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(bits_out, c->stage_out, n, hipMemcpyDeviceToHost, c->stream));
+    return check_err_flag(c, c->slots[slot]);
+}
+
+int tfft_inverse_rgb8_dev(tfft_ctx* c, int slot, void* rgb_out_dev) {
+    if (!slot_ok(c, slot) || !rgb_out_dev) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    return enqueue_inverse(c, s, (uint8_t*)rgb_out_dev, c->stream);
+}
+
+int tfft_inverse_rgb8(tfft_ctx* c, int slot, uint8_t* rgb_out) {
+    if (!slot_ok(c, slot) || !rgb_out) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    int rc = enqueue_inverse(c, s, s.img, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(rgb_out, s.img, (size_t)s.W * s.H * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TFFT_OK;
+}
+
+int tfft_download_spectrum(tfft_ctx* c, int slot, float* out) {
+    if (!slot_ok(c, slot) || !out) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (!s.has_spec) return TFFT_E_STATE;
+    const size_t n = (size_t)3 * s.PH * s.PW;
+    float2* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(float2)) != hipSuccess) return TFFT_E_NOMEM;
+    hipError_t e = launch_export_full(s.spec, s.PH, s.PWi, s.PW, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) { c->last_hip = (int)e; return TFFT_E_HIP; }
+    return TFFT_OK;
+}
+
+// ---------------------------------------------------------------- batches
+static int batch_fork(tfft_ctx* c, int used) {
+    if (c->n_slots == 1) return TFFT_OK;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int i = 0; i < used; i++) HIPCHK(c, hipStreamWaitEvent(c->slots[i].stream, c->ev_fork, 0));
+    return TFFT_OK;
+}
+static int batch_join(tfft_ctx* c, int used) {
+    if (c->n_slots == 1) return TFFT_OK;
+    for (int i = 0; i < used; i++) {
+        HIPCHK(c, hipEventRecord(c->slots[i].done, c->slots[i].stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->slots[i].done, 0));
+    }
+    return TFFT_OK;
+}
+
+int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                         const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                         void* usable_out_dev, void* rgb_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || (n_bits && (!bins_dev || !bits_dev))) return TFFT_E_INVALID;
+    if (n_images == 0) return TFFT_OK;
+    const int used = n_images < c->n_slots ? n_images : c->n_slots;
+    for (int i = 0; i < used; i++) { int rc = set_geometry(c, c->slots[i], w, h, center); if (rc) return rc; }
+    { const float2* t; int rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
+    int rc = batch_fork(c, used);
+    if (rc) return rc;
+    const size_t img_bytes = (size_t)w * h * 3;
+    for (int i = 0; i < n_images; i++) {
+        Slot& s = c->slots[i % c->n_slots];
+        hipStream_t st = (c->n_slots == 1) ? c->stream : s.stream;
+        rc = enqueue_forward(c, s, (const uint8_t*)rgb_dev + (size_t)i * img_bytes, st);
+        if (rc) return rc;
+        if (usable_out_dev) {      // S:922-923, S:998-1012 on the device, no host round trip
+            HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, st));
+            CapParams p = cap_params(s, rmin, rmax);
+            p.magmin = magmin;
+            HIPCHK(c, launch_capacity(s.spec, p, s.med, s.counts, (unsigned long long*)usable_out_dev + i, st));
+        }
+        EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
+        HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev + (size_t)i * n_bits, nullptr, ep, s.err, st));
+        rc = enqueue_inverse(c, s, (uint8_t*)rgb_out_dev + (size_t)i * img_bytes, st);
+        if (rc) return rc;
+    }
+    return batch_join(c, used);
+}
+
+int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                           uint64_t n_bits, double alpha, void* bits_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || (n_bits && (!bins_dev || !bits_out_dev))) return TFFT_E_INVALID;
+    if (n_images == 0) return TFFT_OK;
+    const int used = n_images < c->n_slots ? n_images : c->n_slots;
+    for (int i = 0; i < used; i++) { int rc = set_geometry(c, c->slots[i], w, h, center); if (rc) return rc; }
+    { const float2* t; int rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
+    int rc = batch_fork(c, used);
+    if (rc) return rc;
+    const size_t img_bytes = (size_t)w * h * 3;
+    for (int i = 0; i < n_images; i++) {
+        Slot& s = c->slots[i % c->n_slots];
+        hipStream_t st = (c->n_slots == 1) ? c->stream : s.stream;
+        rc = enqueue_forward(c, s, (const uint8_t*)rgb_dev + (size_t)i * img_bytes, st);
+        if (rc) return rc;
+        EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
+        HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins_dev, nullptr, ep, (uint8_t*)bits_out_dev + (size_t)i * n_bits, s.err, st));
+    }
+    return batch_join(c, used);
+}
+
+int tfft_timer_begin(tfft_ctx* c) {
+    if (!c) return TFFT_E_INVALID;
+    HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+    return TFFT_OK;
+}
+int tfft_timer_end(tfft_ctx* c, float* ms) {
+    if (!c || !ms) return TFFT_E_INVALID;
+    HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_t1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev_t0, c->ev_t1));
+    return TFFT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// tfft_fft.h -- register/LDS Stockham FFT building blocks for gfx950 (wave64).
+//
+// A length-N complex FFT is done by N/E threads, each holding E elements in
+// VGPRs.  Thread t always owns the elements at positions t + m*(N/E), m < E --
+// both on entry (time index) and on exit (frequency index, natural order) --
+// so the first pass can be fed straight from global memory and the last pass
+// can be stored straight back: LDS is touched only for the exchanges between
+// radix passes (Stockham autosort, no bit-reversal pass).
+//
+// Sign convention is the reference's (steganosaur.cpp:347): SIGN=+1 is the
+// "forward" kernel exp(+2*pi*i*nk/N), SIGN=-1 the inverse kernel.  No scaling
+// is applied here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tfft {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+constexpr int bitrev(int v, int bits) { return bits == 0 ? 0 : ((v & 1) << (bits - 1)) | bitrev(v >> 1, bits - 1); }
+constexpr int imin(int a, int b) { return a < b ? a : b; }
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// d * exp(SIGN * 2*pi*i * idx16/16), idx16 in 0..7 (compile-time after unrolling)
+template <int SIGN>
+__device__ __forceinline__ float2 twmul16(float2 d, int idx16) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    constexpr float s = (float)SIGN;
+    switch (idx16) {
+        case 0: return d;
+        case 1: return make_float2(d.x * C1 - s * d.y * S1, s * d.x * S1 + d.y * C1);
+        case 2: return make_float2((d.x - s * d.y) * H, (s * d.x + d.y) * H);
+        case 3: return make_float2(d.x * S1 - s * d.y * C1, s * d.x * C1 + d.y * S1);
+        case 4: return make_float2(-s * d.y, s * d.x);
+        case 5: return make_float2(-d.x * S1 - s * d.y * C1, s * d.x * C1 - d.y * S1);
+        case 6: return make_float2((-d.x - s * d.y) * H, (s * d.x - d.y) * H);
+        default: return make_float2(-d.x * C1 - s * d.y * S1, s * d.x * S1 - d.y * C1);
+    }
+}
+
+// In-register radix-2 DIF network on v[OFF .. OFF+R): result X[q] lands in
+// v[OFF + bitrev(q)].
+template <int R, int SIGN, int OFF, int E>
+struct DftReg {
+    static __device__ __forceinline__ void run(float2 (&v)[E]) {
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) {
+            float2 a = v[OFF + j], b = v[OFF + j + R / 2];
+            v[OFF + j] = cadd(a, b);
+            v[OFF + j + R / 2] = twmul16<SIGN>(csub(a, b), j * (16 / R));
+        }
+        DftReg<R / 2, SIGN, OFF, E>::run(v);
+        DftReg<R / 2, SIGN, OFF + R / 2, E>::run(v);
+    }
+};
+template <int SIGN, int OFF, int E>
+struct DftReg<1, SIGN, OFF, E> {
+    static __device__ __forceinline__ void run(float2 (&)[E]) {}
+};
+
+// LDS layouts.  idx(n, b): element n of sequence b.
+struct LayColumns {   // tile of NB adjacent columns, column index innermost
+    int nb;
+    __device__ __forceinline__ int idx(int n, int b) const { return n * nb + b; }
+};
+struct LayRows {      // sequences back to back, `pitch` float2 apart, one pad slot per 16 elements
+    int pitch;
+    __device__ __forceinline__ int idx(int n, int b) const { return b * pitch + n + (n >> 4); }
+    static constexpr int padded(int n) { return n + (n >> 4) + 1; }
+};
+
+// exp(SIGN*2*pi*i*j/N) from a table tw[j] = exp(+2*pi*i*j/N)
+template <int SIGN>
+__device__ __forceinline__ float2 twload(const float2* __restrict__ tw, int j) {
+    float2 w = tw[j];
+    return SIGN > 0 ? w : cconj(w);
+}
+
+// All radix passes of a length-N FFT for one thread.
+//   u[m] holds x[t + m*T] on entry and X[t + m*T] on exit (T = N/E).
+//   lds/lay: exchange buffer (N elements per sequence);  tw: table for size N.
+//   Every thread of the workgroup must call this (it contains barriers), also
+//   threads whose sequence is out of range.
+template <int N, int E, int SIGN, int P, class Lay>
+struct FftPasses {
+    static constexpr int R = imin(E, N / P);        // radix of this pass
+    static constexpr bool LAST = (P * R == N);
+    static constexpr int T = N / E;
+    static constexpr int Q = E / R;                  // butterflies per thread
+    static __device__ __forceinline__ void run(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
+                                               const float2* __restrict__ tw, int tws) {
+        float2 o[E];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) v[r] = u[q + r * Q];
+            const int i = t + q * T;
+            const int k = i & (P - 1);
+            if constexpr (P > 1) {   // inter-pass twiddles exp(SIGN*2*pi*i*r*k/(P*R)), powers by a balanced product tree
+                float2 w[R];
+                w[1] = twload<SIGN>(tw, k * (N / (P * R)) * tws);
+#pragma unroll
+                for (int r = 2; r < R; r++) w[r] = cmul(w[r / 2], w[(r + 1) / 2]);
+#pragma unroll
+                for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+            }
+            DftReg<R, SIGN, 0, R>::run(v);
+            if constexpr (LAST) {
+#pragma unroll
+                for (int s = 0; s < R; s++) o[q + s * Q] = v[bitrev(s, ilog2(R))];
+            } else {
+                const int j = (i - k) * R + k;
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[lay.idx(j + s * P, b)] = v[bitrev(s, ilog2(R))];
+            }
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = o[m];
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, b)];
+            __syncthreads();
+            FftPasses<N, E, SIGN, P * R, Lay>::run(u, lds, lay, t, b, tw, tws);
+        }
+    }
+};
+
+template <int N, int E, int SIGN, class Lay>
+__device__ __forceinline__ void fft_block(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
+                                          const float2* __restrict__ tw, int tws) {
+    // tw[j*tws] = exp(+2*pi*i*j/N): one table per image dimension serves every sub-length
+    if constexpr (N > 1) FftPasses<N, E, SIGN, 1, Lay>::run(u, lds, lay, t, b, tw, tws);
+}
+
+// elements per thread for a length-N transform
+constexpr int elems_for(int n) { return imin(16, n); }
+
+}  // namespace tfft

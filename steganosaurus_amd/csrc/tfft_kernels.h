@@ -1,0 +1,71 @@
+// tfft_kernels.h -- parameter blocks and launchers shared by tfft_kernels.hip and tfft_capi.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/turtlefft_hip.h"
+
+namespace tfft {
+
+struct RowParams {
+    int W, H;        // image size (pixels)
+    int PW, PH;      // padded size (internal PW >= 2)
+    int center;      // (-1)^(x+y) pre/post multiply (apply_center)
+    float scale;     // inverse only: 1/((PW/2)*PH)
+};
+
+struct ColParams {
+    int M;             // columns of the half spectrum (PW/2)
+    int PH;            // full column length (twiddle table size)
+    int G;             // groups (1 for the direct pass, N2 or N1 for the two-step passes)
+    int in_a, in_b;    // input row  = in_a*l  + in_b*g
+    int out_a, out_b;  // output row = out_a*k + out_b*g
+    int in_rows;       // input rows >= in_rows are zero (not loaded)
+    int out_rows;      // output rows >= out_rows are not stored
+    int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)
+    size_t plane_stride;  // float2 elements between planes (PH*M)
+};
+
+struct EmbedParams {
+    uint64_t n;
+    int PH, PW;
+    int generic;       // 0: alpha fixed, no jitter, 0<alpha<pi -> cos/sin constants and sign test
+    int adaptive;
+    float cos_a, sin_a;
+    double alpha;
+    double med[3];
+};
+
+struct CapParams {
+    int PH, PW;                     // padded grid as the reference sees it
+    int PWi;                        // internal (even) row length used for indexing the half spectrum
+    int bw, bh;                     // bounding box of the annulus (x < bw, y < bh)
+    unsigned long long s_lo, s_hi;  // s_lo <= y*y+x*x <= s_hi  <=>  rmin*mn <= hypot(y,x) <= rmax*mn
+    double magmin;                  // used with med_dev (batch path)
+    double thr[3];                  // used when med_dev == nullptr (tfft_capacity)
+};
+
+struct SelectState {
+    unsigned long long hist[2048];
+    unsigned long long rank;
+    unsigned prefix;
+    unsigned pad;
+};
+
+hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
+                           hipStream_t s);
+hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
+                           hipStream_t s);
+hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
+                       int n_planes, hipStream_t s);
+hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
+                        const EmbedParams& P, int* err, hipStream_t s);
+hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
+                       uint8_t* bits_out, int* err, hipStream_t s);
+hipError_t launch_medians(const float2* spec, int PH, int PW, SelectState* st, float* med_out, hipStream_t s);
+hipError_t launch_capacity(const float2* spec, const CapParams& P, const float* med_dev, unsigned long long* counts,
+                           unsigned long long* usable, hipStream_t s);
+hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);
+hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s);
+
+}  // namespace tfft

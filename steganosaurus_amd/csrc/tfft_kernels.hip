@@ -1,0 +1,564 @@
+// tfft_kernels.hip -- hand-written gfx950 kernels of the TurtleFFT hot path.
+//
+// Data layout in HBM (per resident image = "slot"):
+//   spec[3][PH][M]  float2, M = PW/2: HALF spectrum of each colour plane.  The
+//                   cover is real, so F[-ky][-kx] = conj(F[ky][kx]) and columns
+//                   kx > M are never stored; column 0 holds F[.][0] and F[.][M]
+//                   packed as FFT_col(X[.][0] + i*X[.][M]) (both are spectra of
+//                   real columns and are separable by Hermitian symmetry).
+//   tmp [3][PH][M]  float2: row-pass output / column-pass input (and reverse).
+//
+// A 2-D transform is: rows (real<->half-complex, length PW, done as a complex
+// FFT of length M on packed even/odd samples) + columns (complex, length PH,
+// on M columns).  Rows >= H of the padded image are zero and are neither
+// stored nor loaded; the inverse computes only rows < H and columns < W.
+//
+// Reference lines (steganosaurus/src/steganosaur.cpp) replaced by each kernel
+// are cited as S:<line>.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tfft_fft.h"
+#include "tfft_kernels.h"
+
+namespace tfft {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char tfft_smem[];
+
+// |F| exactly as every kernel of this library computes it (one definition so
+// that medians, capacity and embed agree bit for bit)
+__device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
+
+// ---------------------------------------------------------------------------
+// rows, forward: u8 RGB row -> (optional centring) -> zero-pad -> real FFT of
+// length PW -> M half-spectrum bins per plane.   S:383-386, S:392, S:393-398,
+// and the row loop of fft2d S:361.
+//   grid  (H, 3/PPB, n_images)   block (T, PPB)   T = M/E
+// ---------------------------------------------------------------------------
+template <int LOGM, int PPB>
+__global__ void k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
+                           RowParams P) {
+    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    const int t = threadIdx.x, pb = threadIdx.y;
+    const int y = blockIdx.x, img = blockIdx.z;
+    const int plane0 = blockIdx.y * PPB;
+    const int tid = pb * T + t, nthr = T * PPB;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+
+    // ---- stage the row: bytes -> floats, de-interleaved into the packed (even,odd) layout
+    const size_t rowbase = ((size_t)img * P.H + y) * (size_t)P.W * 3;
+    const uint8_t* src = rgb + rowbase;
+    const int nbytes = P.W * 3;
+    const int head = (int)((4 - ((uintptr_t)src & 3)) & 3);
+    auto put = [&](int off, unsigned byte) {
+        const int n = off / 3, ch = off - 3 * n;
+        const int b = ch - plane0;
+        if (b < 0 || b >= PPB) return;
+        float v = (float)byte;
+        if (P.center && ((n + y) & 1)) v = -v;
+        ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = v;
+    };
+    for (int o = tid; o < head && o < nbytes; o += nthr) put(o, src[o]);
+    const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
+    const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src + head);
+    for (int w = tid; w < nwords; w += nthr) {
+        const uint32_t v = srcw[w];
+        const int o = head + 4 * w;
+        put(o, v & 0xFF); put(o + 1, (v >> 8) & 0xFF); put(o + 2, (v >> 16) & 0xFF); put(o + 3, v >> 24);
+    }
+    for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) put(o, src[o]);
+    for (int n = P.W + tid; n < 2 * M; n += nthr) {   // zero padding W..PW-1
+#pragma unroll
+        for (int b = 0; b < PPB; b++) ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = 0.0f;
+    }
+    __syncthreads();
+
+    // ---- complex FFT of length M on z[m] = x[2m] + i x[2m+1]
+    float2 u[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, pb)];
+    __syncthreads();
+    fft_block<M, E, +1>(u, lds, lay, t, pb, tw, 2);
+#pragma unroll
+    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = u[m];
+    __syncthreads();
+
+    // ---- split into the spectrum of the real row: X[k] = Ev[k] + w^k Od[k], w = exp(+2 pi i/PW)
+    float2* dst = out + (((size_t)img * 3 + plane0 + pb) * P.PH + y) * M;
+    for (int k = t; k <= M / 2; k += T) {
+        const int k2 = (M - k) & (M - 1);
+        const float2 zk = lds[lay.idx(k, pb)], zm = lds[lay.idx(k2, pb)];
+        const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // Ev[k]
+        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                        // zk - conj(zm)
+        const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);                        // Od[k] = d/(2i)
+        const float2 b = cmul(tw[k], od);
+        if (k == 0) {
+            dst[0] = make_float2(a.x + b.x, a.x - b.x);      // X[0] and X[M], both real, packed
+        } else {
+            dst[k] = cadd(a, b);
+            if (k2 != k) dst[k2] = cconj(csub(a, b));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// rows, inverse: M half-spectrum bins -> real row of length PW (only x < W is
+// produced) -> scale -> (centring) -> round half away, clamp, interleave u8.
+// The row loop of fft2d(inverse) S:361/S:357, ifft_crop S:399-403, S:1102,
+// from_planes_u8 S:387-391.
+//   grid  (H, 3/PPB, n_images)   block (T, PPB)
+// ---------------------------------------------------------------------------
+template <int LOGM, int PPB>
+__global__ void k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
+                           RowParams P) {
+    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    const int t = threadIdx.x, pb = threadIdx.y;
+    const int y = blockIdx.x, img = blockIdx.z;
+    const int plane0 = blockIdx.y * PPB;
+    const int tid = pb * T + t, nthr = T * PPB;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+
+    const float2* src = in + (((size_t)img * 3 + plane0 + pb) * P.PH + y) * M;
+    for (int k = t; k < M; k += T) lds[lay.idx(k, pb)] = src[k];
+    __syncthreads();
+
+    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
+    float2 u[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int k = t + m * T;
+        const float2 xk = lds[lay.idx(k, pb)];
+        if (k == 0) {
+            u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));
+        } else {
+            const float2 xm = lds[lay.idx(M - k, pb)];
+            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 od = cmul(d, cconj(tw[k]));
+            u[m] = make_float2(ev.x - od.y, ev.y + od.x);
+        }
+    }
+    __syncthreads();
+    fft_block<M, E, -1>(u, lds, lay, t, pb, tw, 2);
+#pragma unroll
+    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = cscale(u[m], P.scale);
+    __syncthreads();
+
+    // ---- quantise and store
+    const size_t rowbase = ((size_t)img * P.H + y) * (size_t)P.W * 3;
+    uint8_t* dst = rgb + rowbase;
+    const int nbytes = P.W * 3;
+    auto get = [&](int off) -> unsigned {
+        const int n = off / 3, ch = off - 3 * n;
+        float v = ldsf[2 * lay.idx(n >> 1, ch - plane0) + (n & 1)];
+        if (P.center && ((n + y) & 1)) v = -v;
+        v = fminf(255.0f, fmaxf(0.0f, roundf(v)));     // round(): half away from zero (S:389)
+        return (unsigned)v;
+    };
+    if (PPB == 3) {
+        const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
+        for (int o = tid; o < head && o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
+        const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
+        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + head);
+        for (int w = tid; w < nwords; w += nthr) {
+            const int o = head + 4 * w;
+            dstw[w] = get(o) | (get(o + 1) << 8) | (get(o + 2) << 16) | (get(o + 3) << 24);
+        }
+        for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
+    } else {
+        for (int n = tid; n < P.W; n += nthr) dst[3 * n + plane0] = (uint8_t)get(3 * n + plane0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// columns: complex FFTs of length L down a tile of 16 adjacent columns.  One
+// kernel serves the direct pass (L = PH) and both steps of the two-step
+// ("four-step") decomposition PH = N1*N2 used for tall images:
+//   input  row of element l of group g : in_a*l  + in_b*g   (rows >= in_rows read as 0)
+//   output row of element k of group g : out_a*k + out_b*g  (rows >= out_rows not stored)
+//   tw_out: multiply output k of group g by exp(SIGN*2*pi*i*k*g/PH)
+// The column loop of fft2d S:362-365.
+//   grid (ceil(M/16), ceil(G/GPB), n_planes)   block (16, T, GPB)
+// ---------------------------------------------------------------------------
+template <int LOGL, int SIGN>
+__global__ void k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
+                           ColParams P) {
+    constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
+    const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
+    const int col = blockIdx.x * C + c;
+    const int g = blockIdx.y * blockDim.z + gl;
+    const bool active = (col < P.M) && (g < P.G);
+    const size_t plane_off = (size_t)blockIdx.z * P.plane_stride;
+    const float2* src = in + plane_off + col;
+    float2* dst = out + plane_off + col;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem) + (size_t)gl * L * C;
+    LayColumns lay{C};
+
+    float2 u[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int row = P.in_a * (t + m * T) + P.in_b * g;
+        u[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
+    }
+    fft_block<L, E, SIGN>(u, lds, lay, t, c, tw, P.PH >> LOGL);
+    if (!active) return;
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int k = t + m * T;
+        const int row = P.out_a * k + P.out_b * g;
+        if (row < P.out_rows) {
+            float2 v = u[m];
+            if (P.tw_out) v = cmul(v, twload<SIGN>(tw, (k * g) & (P.PH - 1)));
+            dst[(size_t)row * P.M] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// spectrum access helpers (half spectrum + packed column 0)
+// ---------------------------------------------------------------------------
+struct BinRef { size_t idx; bool conj; };
+__device__ __forceinline__ BinRef locate(int plane, int y, int x, int PH, int PW) {
+    const int M = PW >> 1;
+    if (x < M) return BinRef{((size_t)plane * PH + y) * M + x, false};
+    const int yy = (PH - y) & (PH - 1);
+    return BinRef{((size_t)plane * PH + yy) * M + (PW - x), true};
+}
+// F[y][0] and F[y][M] out of the packed column 0
+__device__ __forceinline__ void unpack_col0(const float2* __restrict__ plane, int y, int PH, int M, float2& f0,
+                                            float2& fm) {
+    const float2 a = plane[(size_t)y * M], b = plane[(size_t)((PH - y) & (PH - 1)) * M];
+    f0 = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));           // (a + conj b)/2
+    fm = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));          // (a - conj b)/(2i)
+}
+__device__ __forceinline__ float2 full_bin(const float2* __restrict__ plane, int y, int x, int PH, int PW) {
+    const int M = PW >> 1;
+    if (x == 0 || x == M) {
+        float2 f0, fm; unpack_col0(plane, y, PH, M, f0, fm);
+        return x == 0 ? f0 : fm;
+    }
+    if (x < M) return plane[(size_t)y * M + x];
+    return cconj(plane[(size_t)((PH - y) & (PH - 1)) * M + (PW - x)]);
+}
+
+// write_bit_on_bin S:712-732 over a bin list (the loop body of S:1074-1097).
+__global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ bins, const uint8_t* __restrict__ bits,
+                        const float* __restrict__ jitter, EmbedParams P, int* __restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const tfft_bin bn = bins[i];
+    const int x = bn.x, y = bn.y, p = bn.plane;
+    if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
+        atomicOr(err, 1);     // outside the grid or on an excluded axis (S:698-700): never produced by the walk
+        return;
+    }
+    const BinRef r = locate(p, y, x, P.PH, P.PW);
+    const float2 v = spec[r.idx];
+    const float mag = fmaxf(1e-12f, mag_of(v));
+    const int bit = bits[i];
+    float2 nv;
+    if (!P.generic) {
+        nv = make_float2(mag * P.cos_a, bit ? mag * P.sin_a : -mag * P.sin_a);
+    } else {
+        double alpha = P.alpha;
+        if (P.adaptive) alpha *= fmin(2.0, fmax(0.5, (double)mag / fmax(1e-12, P.med[p])));   // S:704-710
+        const double theta = (bit ? alpha : -alpha) + (jitter ? (double)jitter[i] : 0.0);
+        nv = make_float2((float)((double)mag * cos(theta)), (float)((double)mag * sin(theta)));
+    }
+    spec[r.idx] = r.conj ? cconj(nv) : nv;    // the Hermitian mirror is implicit in the half spectrum
+}
+
+// read_bit_from_bin S:734-746 over a bin list.
+__global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restrict__ bins,
+                       const float* __restrict__ jitter, EmbedParams P, uint8_t* __restrict__ bits_out,
+                       int* __restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const tfft_bin bn = bins[i];
+    const int x = bn.x, y = bn.y, p = bn.plane;
+    if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
+        atomicOr(err, 1);
+        bits_out[i] = 0;
+        return;
+    }
+    const BinRef r = locate(p, y, x, P.PH, P.PW);
+    float2 v = spec[r.idx];
+    if (r.conj) v = cconj(v);
+    int bit;
+    if (!P.generic) {
+        bit = (v.y >= 0.0f) ? 1 : 0;     // nearer of +a / -a for 0 < a < pi, ties -> 1
+    } else {
+        const double PI = 3.14159265358979323846;
+        const double th = atan2((double)v.y, (double)v.x);
+        double alpha = P.alpha;
+        if (P.adaptive) {
+            const double mag = fmax(1e-12, (double)mag_of(v));
+            alpha *= fmin(2.0, fmax(0.5, mag / fmax(1e-12, P.med[p])));
+        }
+        const double j = jitter ? (double)jitter[i] : 0.0;
+        double dp = fmod(th - (j + alpha) + PI, 2 * PI); if (dp < 0) dp += 2 * PI; dp = fabs(dp - PI);
+        double dn = fmod(th - (j - alpha) + PI, 2 * PI); if (dn < 0) dn += 2 * PI; dn = fabs(dn - PI);
+        bit = (dp <= dn) ? 1 : 0;
+    }
+    bits_out[i] = (uint8_t)bit;
+}
+
+// ---------------------------------------------------------------------------
+// median_abs S:404-409: exact order statistic (sorted index P/2) of |F| over
+// the full plane, by a 3-pass radix select on the float bit pattern (11+11+10
+// bits).  Stored bins of columns 1..M-1 count twice (bin + mirror), the packed
+// column 0 yields F[.][0] and F[.][M] once each.
+//   grid (blocks, 3)   block 256;   st = SelectState[3]
+// ---------------------------------------------------------------------------
+template <int PASS>
+__device__ __forceinline__ void hist_add(unsigned* hist, unsigned prefix, float mg, unsigned w) {
+    const unsigned b = __float_as_uint(mg);
+    if (PASS == 0) atomicAdd(&hist[b >> 21], w);
+    else if (PASS == 1) { if ((b >> 21) == prefix) atomicAdd(&hist[(b >> 10) & 2047], w); }
+    else { if ((b >> 10) == prefix) atomicAdd(&hist[b & 1023], w); }
+}
+template <int PASS>
+__global__ void k_mag_hist(const float2* __restrict__ spec, int PH, int M, SelectState* __restrict__ st) {
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 2048 counters (dynamic LDS)
+    const int plane = blockIdx.y;
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const float2* pl = spec + (size_t)plane * PH * M;
+    const unsigned prefix = st[plane].prefix;
+    const size_t n = (size_t)PH * M;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(e / M), x = (int)(e - (size_t)y * M);
+        if (x == 0) {
+            float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
+            hist_add<PASS>(hist, prefix, mag_of(f0), 1); hist_add<PASS>(hist, prefix, mag_of(fm), 1);
+        } else {
+            hist_add<PASS>(hist, prefix, mag_of(pl[e]), 2);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+        if (hist[i]) atomicAdd(&st[plane].hist[i], (unsigned long long)hist[i]);
+}
+// one block per plane: pick the bucket holding the wanted rank, zero the histogram
+template <int PASS>
+__global__ void k_select(SelectState* __restrict__ st, float* __restrict__ med_out) {
+    const int plane = blockIdx.x;
+    SelectState& s = st[plane];
+    if (threadIdx.x == 0) {
+        unsigned long long cum = 0, rank = s.rank;
+        const int nb = (PASS == 2) ? 1024 : 2048;
+        int sel = nb - 1;
+        for (int i = 0; i < nb; i++) {
+            if (cum + s.hist[i] > rank) { sel = i; break; }
+            cum += s.hist[i];
+        }
+        s.rank = rank - cum;
+        s.prefix = (PASS == 0) ? (unsigned)sel : (PASS == 1) ? ((s.prefix << 11) | (unsigned)sel)
+                                                            : ((s.prefix << 10) | (unsigned)sel);
+        if (PASS == 2) med_out[plane] = __uint_as_float(s.prefix);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.hist[i] = 0;
+}
+__global__ void k_select_init(SelectState* __restrict__ st, unsigned long long rank) {
+    SelectState& s = st[blockIdx.x];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.hist[i] = 0;
+    if (threadIdx.x == 0) { s.rank = rank; s.prefix = 0; }
+}
+
+// ---------------------------------------------------------------------------
+// capacity count_plane S:998-1008 over the bounding box of the annulus.
+// The radius test is done on exact integers: s_lo <= y*y+x*x <= s_hi, with the
+// bounds derived on the host from the reference's double comparison.
+//   grid (ceil(bw*bh/256), 3)    thr: magmin*median per plane (double)
+// ---------------------------------------------------------------------------
+__global__ void k_capacity(const float2* __restrict__ spec, CapParams P, const float* __restrict__ med_dev,
+                           unsigned long long* __restrict__ counts) {
+    unsigned& blk = *reinterpret_cast<unsigned*>(tfft_smem);
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
+    const int plane = blockIdx.y;
+    const double thr = med_dev ? P.magmin * (double)med_dev[plane] : P.thr[plane];
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (size_t)P.bw * P.bh) {
+        const int y = (int)(e / P.bw), x = (int)(e - (size_t)y * P.bw);
+        const unsigned long long s = (unsigned long long)y * y + (unsigned long long)x * x;
+        const bool axis = (y == 0 || x == 0 || 2 * y == P.PH || 2 * x == P.PW);
+        if (!axis && s >= P.s_lo && s <= P.s_hi) {
+            const float2 v = full_bin(spec + (size_t)plane * P.PH * (P.PWi >> 1), y, x, P.PH, P.PWi);
+            if (!((double)mag_of(v) < thr)) atomicAdd(&blk, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicAdd(&counts[plane], (unsigned long long)blk);
+}
+// usable = sum_p floor(c_p/2); also resets the counters for the next image
+__global__ void k_capacity_final(unsigned long long* __restrict__ counts, unsigned long long* __restrict__ usable) {
+    if (threadIdx.x == 0) {
+        *usable = counts[0] / 2 + counts[1] / 2 + counts[2] / 2;
+        counts[0] = counts[1] = counts[2] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exports for parity tests and the cover hash (S:428-436)
+// ---------------------------------------------------------------------------
+__global__ void k_export_full(const float2* __restrict__ spec, int PH, int PW, int PWout, float2* __restrict__ out) {
+    const size_t n = (size_t)3 * PH * PWout;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int x = (int)(e % PWout);
+    const int y = (int)((e / PWout) % PH);
+    const int p = (int)(e / ((size_t)PWout * PH));
+    out[e] = full_bin(spec + (size_t)p * PH * (PW >> 1), y, x, PH, PW);
+}
+__global__ void k_lowfreq(const float2* __restrict__ spec, int PH, int PW, int region, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * region * region) return;
+    const int x = e % region, y = (e / region) % region, p = e / (region * region);
+    const float2 v = full_bin(spec + (size_t)p * PH * (PW >> 1), y, x, PH, PW);
+    out[e] = hypot((double)v.x, (double)v.y);
+}
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+#define TFFT_DISPATCH_LOG(n, F)                                                                   \
+    switch (n) {                                                                                  \
+        case 0: F(0); break; case 1: F(1); break; case 2: F(2); break; case 3: F(3); break;       \
+        case 4: F(4); break; case 5: F(5); break; case 6: F(6); break; case 7: F(7); break;       \
+        case 8: F(8); break; case 9: F(9); break; case 10: F(10); break; case 11: F(11); break;   \
+        case 12: F(12); break; case 13: F(13); break;                                             \
+        default: return hipErrorInvalidValue;                                                     \
+    }
+
+constexpr int rows_ppb(int logm) { return logm <= 11 ? 3 : 1; }   // 3 planes/block while 3*M*8 B fits LDS comfortably
+
+template <int LOGM, int PPB, bool FWD>
+static hipError_t launch_rows_t(const void* in, void* out, const float2* tw, const RowParams& P, int n_images,
+                                hipStream_t s) {
+    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    const size_t lds = (size_t)PPB * LayRows::padded(M) * sizeof(float2);
+    dim3 grid(P.H, 3 / PPB, n_images), block(T, PPB, 1);
+    if (FWD) {
+        auto k = k_rows_fwd<LOGM, PPB>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, block, lds, s, (const uint8_t*)in, (float2*)out, tw, P);
+    } else {
+        auto k = k_rows_inv<LOGM, PPB>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, block, lds, s, (const float2*)in, (uint8_t*)out, tw, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
+                           hipStream_t s) {
+    const int logm = ilog2(P.PW >> 1);
+#define F(n) return launch_rows_t<n, rows_ppb(n), true>(rgb, out, tw_pw, P, n_images, s)
+    TFFT_DISPATCH_LOG(logm, F)
+#undef F
+    return hipSuccess;
+}
+hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
+                           hipStream_t s) {
+    const int logm = ilog2(P.PW >> 1);
+#define F(n) return launch_rows_t<n, rows_ppb(n), false>(in, rgb, tw_pw, P, n_images, s)
+    TFFT_DISPATCH_LOG(logm, F)
+#undef F
+    return hipSuccess;
+}
+
+template <int LOGL, int SIGN>
+static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
+                                hipStream_t s) {
+    constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
+    int gpb = 256 / (T * C);
+    if (gpb < 1) gpb = 1;
+    if (gpb > P.G) gpb = P.G;
+    const size_t lds = (size_t)gpb * L * C * sizeof(float2);
+    dim3 grid((P.M + C - 1) / C, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);
+    auto k = k_fft_cols<LOGL, SIGN>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, grid, block, lds, s, in, out, tw, P);
+    return hipGetLastError();
+}
+hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
+                       int n_planes, hipStream_t s) {
+    if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
+#define F(n)                                                                            \
+    return sign > 0 ? launch_cols_t<(n <= 10 ? n : 10), +1>(in, out, tw_ph, P, n_planes, s) \
+                    : launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s)
+    TFFT_DISPATCH_LOG(logl, F)
+#undef F
+    return hipSuccess;
+}
+
+hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
+                        const EmbedParams& P, int* err, hipStream_t s) {
+    if (P.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((P.n + 255) / 256);
+    hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), 0, s, spec, bins, bits, jitter, P, err);
+    return hipGetLastError();
+}
+hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
+                       uint8_t* bits_out, int* err, hipStream_t s) {
+    if (P.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((P.n + 255) / 256);
+    hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, s, spec, bins, jitter, P, bits_out, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_medians(const float2* spec, int PH, int PW, SelectState* st, float* med_out, hipStream_t s) {
+    const int M = PW >> 1;
+    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
+    const size_t n = (size_t)PH * M;
+    unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_select_init, dim3(3), dim3(256), 0, s, st, rank);
+    hipLaunchKernelGGL(k_mag_hist<0>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
+    hipLaunchKernelGGL(k_select<0>, dim3(3), dim3(256), 0, s, st, med_out);
+    hipLaunchKernelGGL(k_mag_hist<1>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
+    hipLaunchKernelGGL(k_select<1>, dim3(3), dim3(256), 0, s, st, med_out);
+    hipLaunchKernelGGL(k_mag_hist<2>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
+    hipLaunchKernelGGL(k_select<2>, dim3(3), dim3(256), 0, s, st, med_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_capacity(const float2* spec, const CapParams& P, const float* med_dev, unsigned long long* counts,
+                           unsigned long long* usable, hipStream_t s) {
+    const size_t n = (size_t)P.bw * P.bh;
+    if (n) {
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_capacity, dim3(blocks, 3), dim3(256), 16, s, spec, P, med_dev, counts);
+    }
+    hipLaunchKernelGGL(k_capacity_final, dim3(1), dim3(64), 0, s, counts, usable);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s) {
+    const size_t n = (size_t)3 * PH * PWout;
+    hipLaunchKernelGGL(k_export_full, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spec, PH, PW, PWout, out);
+    return hipGetLastError();
+}
+hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s) {
+    const int n = 3 * region * region;
+    hipLaunchKernelGGL(k_lowfreq, dim3((n + 255) / 256), dim3(256), 0, s, spec, PH, PW, region, out);
+    return hipGetLastError();
+}
+
+}  // namespace tfft

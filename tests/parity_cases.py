@@ -1,0 +1,215 @@
+"""Parity checks of the HIP path against the oracle / golden vectors, written once
+and run twice: on a real MI355X through libturtlefft_hip.so (tests/test_gpu_parity.py,
+-m gpu) and on the CPU-emulated build of the same kernel sources
+(tests/test_emulated.py), where they check index math only.
+
+Bars (north_star): extracted bits bit-exact; FFT coefficients within 1e-4 relative.
+"""
+import hashlib
+import os
+
+import numpy as np
+
+from _checkers import Params, bins_digest
+from steganosaurus_amd import binding as B
+from steganosaurus_amd.synth import cover_rgb, gradient_cover, secret_ascii, n_stream_bits
+
+PASS = "test123"
+PK = hashlib.sha256(PASS.encode()).digest()
+
+
+def spec_errors(got, want):
+    """(normwise relative error, worst per-coefficient relative error).  The per-coefficient
+    figure is taken over coefficients of at least 1 % of the plane's rms magnitude: below
+    that an fp32 transform sits on its rounding floor (~1e-7 * rms absolute), which the
+    normwise bound covers."""
+    want = np.asarray(want)
+    got = np.asarray(got).astype(np.complex128)
+    nrm = np.linalg.norm(got - want) / max(1e-300, np.linalg.norm(want))
+    rms = np.sqrt(np.mean(np.abs(want) ** 2))
+    big = np.abs(want) >= 1e-2 * rms
+    rel = (np.abs(got - want)[big] / np.abs(want)[big]).max() if big.any() else 0.0
+    return nrm, rel
+
+
+def assert_spectrum_close(got, want, tag=""):
+    nrm, rel = spec_errors(got, want)
+    assert nrm < 2e-6, (tag, "normwise", nrm)
+    assert rel < 1e-4, (tag, "per-coefficient", rel)     # the north_star tolerance
+
+
+def check_fft_kat(lib):
+    """delta at (y=1,x=1) on 4x8: F[0][1] = (+.7071,+.7071), F[1][0] = (0,+1) (SURVEY finding 3)."""
+    img = np.zeros((4, 8, 3), np.uint8)
+    img[1, 1, :] = 1
+    ctx = B.Context(8, 4, lib=lib)
+    pw, ph = ctx.forward_rgb8(img)
+    assert (pw, ph) == (8, 4)
+    F = ctx.download_spectrum(pw, ph)
+    for p in range(3):
+        assert abs(F[p, 0, 1] - (0.70710678 + 0.70710678j)) < 1e-6
+        assert abs(F[p, 1, 0] - 1j) < 1e-6
+    ctx.close()
+
+
+def check_forward_against_oracle(lib, orc, sizes, centers=(0, 1)):
+    for (w, h) in sizes:
+        img = cover_rgb(w, h, 0)
+        ctx = B.Context(w, h, lib=lib)
+        for center in centers:
+            want, med = orc.forward_rgb8(img, center)
+            pw, ph = ctx.forward_rgb8(img, center)
+            assert (ph, pw) == want.shape[1:]
+            got = ctx.download_spectrum(pw, ph)
+            for p in range(3):
+                assert_spectrum_close(got[p], want[p], (w, h, center, p))
+            gm = ctx.medians()
+            assert np.allclose(gm, med, rtol=2e-6), (w, h, gm, med)
+            cap_want, _ = orc.capacity_rgb8(img, Params(center=center))
+            cap = ctx.capacity(0.01 * gm)
+            assert abs(cap - cap_want) <= 2, (w, h, cap, cap_want)
+        ctx.close()
+
+
+def check_forward_golden(lib, golden_dir, wh, center):
+    g = np.load(os.path.join(golden_dir, f"fft_{wh[0]}x{wh[1]}_c{center}.npz"))
+    img = cover_rgb(wh[0], wh[1], int(g["cover_index"]))
+    ctx = B.Context(wh[0], wh[1], lib=lib)
+    pw, ph = ctx.forward_rgb8(img, center)
+    got = ctx.download_spectrum(pw, ph)
+    for p in range(3):
+        assert_spectrum_close(got[p], g["spec"][p], (wh, center, p))
+    assert np.allclose(ctx.medians(), g["med"], rtol=2e-6)
+    ctx.close()
+
+
+def check_identity_roundtrip(lib, sizes):
+    """forward -> inverse with no embedding returns the cover exactly (integers survive fp32)."""
+    for (w, h) in sizes:
+        img = cover_rgb(w, h, 1)
+        ctx = B.Context(w, h, lib=lib)
+        for center in (0, 1):
+            ctx.forward_rgb8(img, center)
+            out = ctx.inverse_rgb8(w, h)
+            assert np.array_equal(out, img), (w, h, center, int((out != img).sum()))
+        ctx.close()
+
+
+def check_walk_against_oracle(lib, orc, cases):
+    kw = orc.subkeys(PK)[0]
+    for (ph, pw, n, rmin, rmax, dens) in cases:
+        rc, want, sk, ctr, start = orc.walk(kw, ph, pw, n, rmin, rmax, dens)
+        assert rc == 0
+        wk = B.Walk(kw, ph, pw, rmin, rmax, dens, lib=lib)
+        assert list(wk.start()) == start.tolist()
+        # resumable: two chunks == one call
+        a = wk.next(n // 3)
+        b = wk.next(n - n // 3)
+        got = B.bins_to_triples(np.concatenate([a, b]))
+        assert np.array_equal(got, want), (ph, pw)
+        assert wk.skipped == sk and wk.ks_blocks() == ctr
+        wk.close()
+
+
+def check_embed_extract(lib, orc, w, h, n_bits, params_kw, seed=3, gradient=False):
+    """GPU embed vs oracle embed on the same cover/bits; GPU read of the oracle's
+    stego vs oracle's raw bits (bit-exact); and the full GPU->GPU round trip."""
+    P = Params(**params_kw)
+    img = gradient_cover(w, h, seed) if gradient else cover_rgb(w, h, seed)
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, n_bits).astype(np.uint8)
+    want_stego, want_spec, want_bins = orc.embed_rgb8(img, PK, bits, P, want_spec=True, want_bins=True)
+    want_raw = orc.extract_bits(want_stego, PK, n_bits, P)
+    sub = orc.subkeys(PK)
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+
+    wk = B.Walk(sub[0], ph, pw, P.rmin, P.rmax, P.density, lib=lib)
+    bins = wk.next(n_bits)
+    assert np.array_equal(B.bins_to_triples(bins), want_bins)
+    jit = B.walk_jitter(sub[1] + sub[2] + sub[3], bins, P.jitter, lib=lib) if P.jitter != 0.0 else None
+
+    ctx = B.Context(w, h, lib=lib)
+    ctx.forward_rgb8(img, P.center)
+    med = ctx.medians()
+    ctx.embed_bins(bins, bits, P.alpha, jit, P.adaptive_alpha, med)
+    got_spec = ctx.download_spectrum(pw, ph)
+    for p in range(3):
+        assert_spectrum_close(got_spec[p], want_spec[p], ("after-embed", w, h, p))
+    stego = ctx.inverse_rgb8(w, h)
+    diff = stego.astype(np.int16) - want_stego
+    assert np.abs(diff).max() <= 1, ("stego differs by more than 1 LSB", np.abs(diff).max())
+    frac = float((diff != 0).mean())
+    assert frac < 0.01, ("fraction of +-1 LSB pixels vs the fp64 reference", frac)
+
+    # GPU read of the ORACLE's stego: raw bits identical to the oracle's raw bits
+    ctx.forward_rgb8(want_stego, P.center)
+    med2 = ctx.medians()
+    got_raw = ctx.read_bins(bins, P.alpha, jit, P.adaptive_alpha, med2)
+    bad = np.nonzero(got_raw != want_raw)[0]
+    if len(bad):
+        # a disagreement is only tolerable where the reference's own decision is a coin flip
+        spec2, _ = orc.forward_rgb8(want_stego, P.center)
+        t = B.bins_to_triples(bins[bad])
+        v = spec2[t[:, 0], t[:, 1], t[:, 2]]
+        assert P.jitter == 0 and not P.adaptive_alpha and np.all(np.abs(v.imag) < 1e-5 * np.abs(v)), (len(bad), v[:4])
+    # GPU -> GPU round trip: same bit-error pattern class as the reference (pow2: few errors)
+    ctx.forward_rgb8(stego, P.center)
+    rt = ctx.read_bins(bins, P.alpha, jit, P.adaptive_alpha, ctx.medians())
+    ctx.close()
+    return {"ber_gpu": float((rt != bits).mean()), "ber_ref": float((want_raw != bits).mean()), "lsb_frac": frac}
+
+
+def check_config1_golden(lib, orc, golden_dir, name):
+    """BASELINE.json configs[0]: 512x512, 1 KB secret, defaults; bits from the reference's own framing."""
+    g = np.load(os.path.join(golden_dir, f"embed_512_{name}.npz"))
+    img = cover_rgb(512, 512, 0) if name == "lcg" else gradient_cover(512, 512, 1)
+    n = int(g["n_bits"])
+    bits = np.unpackbits(g["bits"])[:n]
+    ref_stego = (img.astype(np.int16) + g["stego_diff"]).astype(np.uint8)
+    ref_raw = np.unpackbits(g["raw"])[:n]
+    sub = orc.subkeys(PK)
+    wk = B.Walk(sub[0], 512, 512, lib=lib)
+    bins = wk.next(n)
+    assert bins_digest(B.bins_to_triples(bins)) == str(g["bins_sha256"])
+    ctx = B.Context(512, 512, lib=lib)
+    # extract side on the reference-made stego: raw bits identical
+    ctx.forward_rgb8(ref_stego)
+    got = ctx.read_bins(bins)
+    assert np.array_equal(got, ref_raw), int((got != ref_raw).sum())
+    # embed side
+    ctx.forward_rgb8(img)
+    ctx.embed_bins(bins, bits)
+    stego = ctx.inverse_rgb8(512, 512)
+    d = stego.astype(np.int16) - ref_stego
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01, (np.abs(d).max(), (d != 0).mean())
+    # the oracle (= reference) extracts the GPU-made stego: payload survives ECC exactly like the reference's
+    back = orc.extract_bits(stego, PK, n)
+    ctx.close()
+    return back, bits, ref_raw
+
+
+def check_error_paths(lib):
+    ctx = B.Context(64, 64, lib=lib)
+    try:
+        ctx.medians()
+        raise AssertionError("medians before forward must fail")
+    except B.TfftError as e:
+        assert e.status == -6
+    try:
+        ctx.forward_rgb8(np.zeros((65, 64, 3), np.uint8))
+        raise AssertionError("oversize image must fail")
+    except B.TfftError as e:
+        assert e.status == -3
+    ctx.forward_rgb8(np.zeros((64, 64, 3), np.uint8))
+    bad = B.make_bins(np.array([[0, 0, 5]]))         # y == 0: excluded axis
+    try:
+        ctx.embed_bins(bad, np.array([1], np.uint8))
+        raise AssertionError("axis bin must be rejected")
+    except B.TfftError as e:
+        assert e.status == -8
+    ctx.close()
+    try:
+        B.Context(70000, 8, lib=lib)
+        raise AssertionError("too large")
+    except B.TfftError as e:
+        assert e.status == -3
