@@ -53,6 +53,7 @@ SYMBOLS = {
     "tfft_walk_ks_blocks": (C.c_uint32, [_vp]),
     "tfft_walk_destroy": (_i, [_vp]),
     "tfft_walk_jitter": (_i, [C.c_char_p, _vp, _u64, _d, _vp]),
+    "tfft_profile_stage": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _d, C.POINTER(C.c_float), _pi]),
     "tfft_timer_begin": (_i, [_vp]),
     "tfft_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
 }
@@ -258,6 +259,19 @@ class Context:
     def extract_batch_dev(self, n_images, rgb_ptr, w, h, bins_ptr, n_bits, bits_out_ptr, alpha=0.5, center=False):
         _check(self.lib.tfft_extract_batch_dev(self.h, n_images, _ptr(rgb_ptr), w, h, int(center), _ptr(bins_ptr),
                                                n_bits, alpha, _ptr(bits_out_ptr)), "tfft_extract_batch_dev")
+
+    STAGES = ["rows_fwd", "cols_fwd_a", "cols_fwd_b", "embed", "cols_inv_a", "cols_inv_b", "rows_inv", "read",
+              "medians", "capacity"]
+
+    def profile_stage(self, stage, reps, rgb_ptr=None, out_ptr=None, bins_ptr=None, bits_ptr=None, bits_out_ptr=None,
+                      n_bits=0, alpha=0.5, slot=0):
+        """Mean ms of one repetition of pipeline stage `stage` (HIP events on the context stream) and
+        the number of kernel launches per repetition."""
+        ms, nl = C.c_float(0), C.c_int(0)
+        _check(self.lib.tfft_profile_stage(self.h, slot, stage, reps, _ptr(rgb_ptr), _ptr(out_ptr), _ptr(bins_ptr),
+                                           _ptr(bits_ptr), _ptr(bits_out_ptr), n_bits, alpha, C.byref(ms),
+                                           C.byref(nl)), "tfft_profile_stage")
+        return ms.value, nl.value
 
     def timer_begin(self):
         _check(self.lib.tfft_timer_begin(self.h), "tfft_timer_begin")

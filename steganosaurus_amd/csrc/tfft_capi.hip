@@ -113,28 +113,71 @@ int set_geometry(tfft_ctx* c, Slot& s, int w, int h, int center) {
     return TFFT_OK;
 }
 
-// forward: rows (u8 -> tmp) then columns (tmp -> spec)
-int enqueue_forward(tfft_ctx* c, Slot& s, const uint8_t* rgb_dev, hipStream_t st) {
+// The single-image pipeline as addressable stages (also used by tfft_profile_stage).
+//   forward : ROWS_FWD (u8 -> tmp), COLS_FWD_A (tmp -> tmp | spec), COLS_FWD_B (tmp -> spec, two-step only)
+//   inverse : COLS_INV_A (spec -> tmp), COLS_INV_B (tmp -> tmp, two-step only), ROWS_INV (tmp -> u8)
+enum Stage { ROWS_FWD = 0, COLS_FWD_A = 1, COLS_FWD_B = 2, EMBED = 3, COLS_INV_A = 4, COLS_INV_B = 5, ROWS_INV = 6,
+             READ = 7, MEDIANS = 8, CAPACITY = 9, N_STAGES = 10 };
+
+int enqueue_fft_stage(tfft_ctx* c, Slot& s, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
     const int M = s.PWi / 2;
     const float2 *tw_w, *tw_h;
     int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
     rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
-    RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f};
-    HIPCHK(c, launch_rows_fwd(rgb_dev, s.tmp, tw_w, rp, 1, st));
     const ColPlan pl = plan_cols(c, s.PH);
+    const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
     ColParams cp{};
     cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M;
-    if (pl.direct) {
-        cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
-        HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
-    } else {
-        const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
-        // step 1: for every n2, length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
-        cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
-        HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, +1, 3, st));
-        // step 2: for every k1, length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
-        cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
-        HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+    switch (stage) {
+        case ROWS_FWD: {
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f};
+            HIPCHK(c, launch_rows_fwd(rgb_in, s.tmp, tw_w, rp, 1, st));
+            return TFFT_OK;
+        }
+        case COLS_FWD_A:
+            if (pl.direct) {
+                cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
+                HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+            } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
+                cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
+                HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, +1, 3, st));
+            }
+            return TFFT_OK;
+        case COLS_FWD_B:
+            if (pl.direct) return TFFT_OK;
+            // for every k1: length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
+            cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
+            HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+            return TFFT_OK;
+        case COLS_INV_A:
+            if (pl.direct) {
+                cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
+                HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+            } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
+                cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
+                HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+            }
+            return TFFT_OK;
+        case COLS_INV_B:
+            if (pl.direct) return TFFT_OK;
+            // for every n2: length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
+            cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
+            HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, -1, 3, st));
+            return TFFT_OK;
+        case ROWS_INV: {
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH))};
+            HIPCHK(c, launch_rows_inv(s.tmp, rgb_out, tw_w, rp, 1, st));
+            return TFFT_OK;
+        }
+        default: return TFFT_E_INVALID;
+    }
+}
+
+// forward: rows (u8 -> tmp) then columns (tmp -> spec)
+int enqueue_forward(tfft_ctx* c, Slot& s, const uint8_t* rgb_dev, hipStream_t st) {
+    for (int stage : {ROWS_FWD, COLS_FWD_A, COLS_FWD_B}) {
+        int rc = enqueue_fft_stage(c, s, stage, rgb_dev, nullptr, st);
+        if (rc) return rc;
     }
     s.has_spec = true;
     return TFFT_OK;
@@ -142,27 +185,10 @@ int enqueue_forward(tfft_ctx* c, Slot& s, const uint8_t* rgb_dev, hipStream_t st
 
 // inverse: columns (spec -> tmp, only rows < H kept) then rows (tmp -> u8)
 int enqueue_inverse(tfft_ctx* c, Slot& s, uint8_t* rgb_out_dev, hipStream_t st) {
-    const int M = s.PWi / 2;
-    const float2 *tw_w, *tw_h;
-    int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
-    rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
-    const ColPlan pl = plan_cols(c, s.PH);
-    ColParams cp{};
-    cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M;
-    if (pl.direct) {
-        cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-        HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
-    } else {
-        const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
-        // step 1: for every k1, length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
-        cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
-        HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
-        // step 2: for every n2, length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
-        cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-        HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, -1, 3, st));
+    for (int stage : {COLS_INV_A, COLS_INV_B, ROWS_INV}) {
+        int rc = enqueue_fft_stage(c, s, stage, nullptr, rgb_out_dev, st);
+        if (rc) return rc;
     }
-    RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH))};
-    HIPCHK(c, launch_rows_inv(s.tmp, rgb_out_dev, tw_w, rp, 1, st));
     s.has_spec = false;
     return TFFT_OK;
 }
@@ -540,6 +566,54 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
         HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins_dev, nullptr, ep, (uint8_t*)bits_out_dev + (size_t)i * n_bits, s.err, st));
     }
     return batch_join(c, used);
+}
+
+int tfft_profile_stage(tfft_ctx* c, int slot, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
+                       const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,
+                       float* ms_per_launch, int* n_launches) {
+    if (!slot_ok(c, slot) || reps < 1 || !ms_per_launch || stage < 0 || stage >= N_STAGES) return TFFT_E_INVALID;
+    Slot& s = c->slots[slot];
+    if (s.PH == 0) return TFFT_E_STATE;
+    const ColPlan pl = plan_cols(c, s.PH);
+    int launches = 1;
+    if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
+    if (stage == MEDIANS) launches = 7;
+    if (stage == CAPACITY) launches = 2;
+    if (n_launches) *n_launches = launches;
+    *ms_per_launch = 0.f;
+    if (launches == 0) return TFFT_OK;
+    { const float2* t; int rc = get_twiddles(c, s.PWi, &t); if (rc) return rc; rc = get_twiddles(c, s.PH, &t); if (rc) return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+    for (int r = 0; r < reps; r++) {
+        int rc = TFFT_OK;
+        switch (stage) {
+            case EMBED: {
+                EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
+                HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev, nullptr, ep, s.err, c->stream));
+                break;
+            }
+            case READ: {
+                EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
+                HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins_dev, nullptr, ep, (uint8_t*)bits_out_dev, s.err, c->stream));
+                break;
+            }
+            case MEDIANS: HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, c->stream)); break;
+            case CAPACITY: {
+                CapParams p = cap_params(s, 0.05, 0.45);
+                p.magmin = 0.01;
+                HIPCHK(c, launch_capacity(s.spec, p, s.med, s.counts, s.usable, c->stream));
+                break;
+            }
+            default: rc = enqueue_fft_stage(c, s, stage, (const uint8_t*)rgb_dev, (uint8_t*)rgb_out_dev, c->stream);
+        }
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_t1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    *ms_per_launch = ms / (float)reps;
+    return TFFT_OK;
 }
 
 int tfft_timer_begin(tfft_ctx* c) {

@@ -399,8 +399,11 @@ __global__ void k_capacity(const float2* __restrict__ spec, CapParams P, const f
 // usable = sum_p floor(c_p/2); also resets the counters for the next image
 __global__ void k_capacity_final(unsigned long long* __restrict__ counts, unsigned long long* __restrict__ usable) {
     if (threadIdx.x == 0) {
-        *usable = counts[0] / 2 + counts[1] / 2 + counts[2] / 2;
-        counts[0] = counts[1] = counts[2] = 0;
+        // read-and-reset with atomics: a plain load followed by a plain store of 0 was compiled to an
+        // un-waited scalar load racing the vector store (SMEM and VMEM are not ordered with each other)
+        const unsigned long long c0 = atomicExch(&counts[0], 0ull), c1 = atomicExch(&counts[1], 0ull),
+                                 c2 = atomicExch(&counts[2], 0ull);
+        *usable = c0 / 2 + c1 / 2 + c2 / 2;
     }
 }
 
