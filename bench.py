@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="1080p_batch", choices=sorted(WORKLOADS))
     ap.add_argument("--images", type=int, default=0, help="images per GPU (default: the workload's)")
-    ap.add_argument("--slots", type=int, default=4, help="pipeline slots (= HIP streams) per GPU")
+    ap.add_argument("--slots", type=int, default=0, help="resident images per launch (default: the whole per-GPU batch, at most 32)")
     ap.add_argument("--no-stats", action="store_true", help="skip medians+capacity inside embed (not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-reps", type=int, default=20)
@@ -136,7 +136,7 @@ def main():
     d_raw = torch.empty((n_img, n_bits), dtype=torch.uint8, device=dev)
     d_usable = torch.zeros(n_img, dtype=torch.int64, device=dev)
 
-    slots = max(1, min(args.slots, n_img))
+    slots = max(1, min(args.slots if args.slots > 0 else 32, n_img))
     ctx = S.Context(W, H, slots=slots, device=local)
     stream = torch.cuda.Stream(device=dev)          # the context runs on this torch-visible HIP stream
     torch.cuda.set_stream(stream)
@@ -183,7 +183,7 @@ def main():
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "describes": wl_desc, "image": [W, H], "padded": [PW, PH],
-                   "payload_bytes": secret, "n_bits": n_bits, "images_per_gpu": n_img, "pipeline_slots": slots,
+                   "payload_bytes": secret, "n_bits": n_bits, "images_per_gpu": n_img, "images_per_launch": slots,
                    "stats_in_embed": not args.no_stats, "parallelism": "independent images per rank, no data-path collective",
                    "host_walk_s": round(t_walk, 3)},
         "roundtrip_ber": ber, "min_capacity_bits": usable_min,
@@ -193,22 +193,20 @@ def main():
     }
 
     if rank == 0:
-        # ---- per-kernel timing with HIP events on the stream the kernels run on (tfft_profile_stage)
-        one = S.Context(W, H, slots=1, device=local)
-        one.set_stream(torch.cuda.current_stream().cuda_stream)
-        one.forward_rgb8_dev(d_img.data_ptr(), W, H)
-        one.sync()
+        # ---- per-kernel timing with HIP events on the stream the kernels run on (tfft_profile_stage):
+        # each stage is ONE batched launch over the chunk of `slots` images, exactly as in the timed step
+        ctx.forward_rgb8_dev(d_img.data_ptr(), W, H)
+        ctx.sync()
         two_step = PH > 512 and not os.environ.get("TFFT_COLS_DIRECT_MAX_LOG")
         stages = {}
         for sid, name in enumerate(S.Context.STAGES):
-            ms, nl = one.profile_stage(sid, args.stage_reps, d_img.data_ptr(), d_stego.data_ptr(), d_bins.data_ptr(),
-                                       d_bits.data_ptr(), d_raw.data_ptr(), n_bits)
+            ms, nl = ctx.profile_stage(sid, args.stage_reps, d_img.data_ptr(), d_stego.data_ptr(), d_bins.data_ptr(),
+                                       d_bits.data_ptr(), d_raw.data_ptr(), n_bits, n_images=slots)
             if nl == 0:
                 continue
-            kb = kernel_bytes(name, W, H, n_bits, two_step)
-            stages[name] = {"ms": round(ms, 5), "launches": nl, "kernel_bytes": kb,
+            kb = kernel_bytes(name, W, H, n_bits, two_step) * slots
+            stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots, "kernel_bytes": kb,
                             "GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-        one.close()
         fft_stages = {k: v for k, v in stages.items() if k.startswith(("rows", "cols"))}
         dom = max(fft_stages, key=lambda k: fft_stages[k]["ms"])
         d = stages[dom]

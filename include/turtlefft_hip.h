@@ -128,8 +128,9 @@ int tfft_download_spectrum(tfft_ctx* ctx, int slot, float* out);
 
 /* ------------------------------------------------------------------ batches
  * n independent images of identical size sharing ONE bin list (the walk does
- * not depend on image content: S:797-799).  Images are pipelined over the
- * context's slots, one HIP stream per slot.  All pointers are device pointers;
+ * not depend on image content: S:797-799).  Images are processed in chunks of
+ * n_slots; every pipeline stage of a chunk is ONE kernel launch over all its
+ * images, on the context's stream.  All pointers are device pointers;
  * image i is at rgb + i*w*h*3, its bits at bits + i*n_bits.
  *   embed  : forward -> [medians+capacity when usable_out != NULL] -> embed -> inverse
  *   extract: forward -> read
@@ -164,17 +165,17 @@ int tfft_walk_jitter(const uint8_t keys_rgb[96], const tfft_bin* bins, uint64_t 
  * context's stream (hipEvent pair on that stream). */
 int tfft_timer_begin(tfft_ctx* ctx);
 /* Per-kernel timing for the roofline report: enqueue stage `stage` of the
- * single-image pipeline `reps` times on the context's stream between two HIP
- * events and return the mean time of ONE repetition (ms) and how many kernel
- * launches one repetition is.  The slot must have been through a forward call
- * (geometry and buffers are reused; results of the repeated stage are
- * discarded by the caller).  Stages: 0 rows_fwd, 1 cols_fwd step A (or the
- * direct column pass), 2 cols_fwd step B, 3 embed, 4 cols_inv step A, 5
- * cols_inv step B, 6 rows_inv, 7 read, 8 medians (7 launches), 9 capacity. */
-int tfft_profile_stage(tfft_ctx* ctx, int slot, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
+ * batched pipeline over slots [0, n_images) `reps` times on the context's stream
+ * between two HIP events; returns the mean time of ONE repetition (ms) and how
+ * many kernel launches one repetition is.  Slot 0 must have been through a
+ * forward call (its geometry is reused for the whole batch; results of the
+ * repeated stage are discarded by the caller).  Stages: 0 rows_fwd, 1 cols_fwd
+ * step A (or the direct column pass), 2 cols_fwd step B, 3 embed, 4 cols_inv
+ * step A, 5 cols_inv step B, 6 rows_inv, 7 read, 8 medians (7 launches),
+ * 9 capacity (2 launches). */
+int tfft_profile_stage(tfft_ctx* ctx, int n_images, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
                        const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,
-                       float* ms_per_launch, int* n_launches);
-int tfft_timer_end(tfft_ctx* ctx, float* ms);
+                       float* ms_per_rep, int* n_launches);
 
 #ifdef __cplusplus
 }

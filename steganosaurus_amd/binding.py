@@ -264,11 +264,11 @@ class Context:
               "medians", "capacity"]
 
     def profile_stage(self, stage, reps, rgb_ptr=None, out_ptr=None, bins_ptr=None, bits_ptr=None, bits_out_ptr=None,
-                      n_bits=0, alpha=0.5, slot=0):
-        """Mean ms of one repetition of pipeline stage `stage` (HIP events on the context stream) and
-        the number of kernel launches per repetition."""
+                      n_bits=0, alpha=0.5, n_images=1):
+        """Mean ms of one repetition of pipeline stage `stage` over slots [0, n_images) (HIP events on
+        the context stream) and the number of kernel launches per repetition."""
         ms, nl = C.c_float(0), C.c_int(0)
-        _check(self.lib.tfft_profile_stage(self.h, slot, stage, reps, _ptr(rgb_ptr), _ptr(out_ptr), _ptr(bins_ptr),
+        _check(self.lib.tfft_profile_stage(self.h, n_images, stage, reps, _ptr(rgb_ptr), _ptr(out_ptr), _ptr(bins_ptr),
                                            _ptr(bits_ptr), _ptr(bits_out_ptr), n_bits, alpha, C.byref(ms),
                                            C.byref(nl)), "tfft_profile_stage")
         return ms.value, nl.value

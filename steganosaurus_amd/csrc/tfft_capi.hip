@@ -23,17 +23,7 @@ using namespace tfft;
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }        // S:369
 int ilog2i(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
-struct Slot {
-    uint8_t* img = nullptr;        // W*H*3 staging (host-pointer API) / output
-    float2* spec = nullptr;        // [3][PH][M]
-    float2* tmp = nullptr;         // [3][PH][M]
-    SelectState* sel = nullptr;    // [3]
-    float* med = nullptr;          // [3] medians of |F| (float bit-exact order statistic)
-    unsigned long long* counts = nullptr;   // [3] capacity counters
-    unsigned long long* usable = nullptr;   // [1]
-    int* err = nullptr;            // [1] sticky bin-range flag
-    hipStream_t stream = nullptr;  // pipeline stream of this slot (batch API)
-    hipEvent_t done = nullptr;
+struct Slot {     // geometry of one resident image; its buffers are slices of the context pools
     int W = 0, H = 0, PW = 0, PH = 0, PWi = 0, center = 0;
     bool has_spec = false;
 };
@@ -47,16 +37,32 @@ struct tfft_ctx {
     int max_w = 0, max_h = 0, n_slots = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_fork = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     int last_hip = 0;
     size_t dev_bytes = 0;
     std::vector<Slot> slots;
-    std::map<int, float2*> tw;           // N -> table exp(+2 pi i j/N), j < N
-    // staging for the host-pointer embed/read API
+    // pools, slot i = slice i (fixed strides so that a run of slots is one batched launch)
+    size_t img_stride_b = 0;      // bytes between slots in img_pool
+    size_t slot_stride = 0;       // float2 elements between slots in spec_pool / tmp_pool
+    size_t cand_stride = 0;       // unsigned elements per (slot, plane) in cand_pool
+    uint8_t* img_pool = nullptr;
+    float2* spec_pool = nullptr;
+    float2* tmp_pool = nullptr;
+    unsigned* cand_pool = nullptr;
+    SelectState* sel = nullptr;           // [n_slots*3]
+    float* med = nullptr;                 // [n_slots*3]
+    unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS]
+    unsigned long long* usable = nullptr; // [n_slots]
+    int* err = nullptr;                   // sticky bin-range flag
+    std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
-    int cols_direct_max_log = 9;         // PH <= 512: one column pass; taller: two-step N1 x N2
+    int cols_direct_max_log = 9;          // PH <= 512: one column pass; taller: two-step N1 x N2
     int cols_force_log_n1 = -1;
+
+    uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
+    float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
+    float2* tmp(int i) const { return tmp_pool + (size_t)i * slot_stride; }
 };
 
 namespace {
@@ -113,87 +119,91 @@ int set_geometry(tfft_ctx* c, Slot& s, int w, int h, int center) {
     return TFFT_OK;
 }
 
-// The single-image pipeline as addressable stages (also used by tfft_profile_stage).
+// The pipeline as addressable stages, each ONE batched launch over slots [s0, s0+n) of equal geometry
+// (also used by tfft_profile_stage).
 //   forward : ROWS_FWD (u8 -> tmp), COLS_FWD_A (tmp -> tmp | spec), COLS_FWD_B (tmp -> spec, two-step only)
 //   inverse : COLS_INV_A (spec -> tmp), COLS_INV_B (tmp -> tmp, two-step only), ROWS_INV (tmp -> u8)
 enum Stage { ROWS_FWD = 0, COLS_FWD_A = 1, COLS_FWD_B = 2, EMBED = 3, COLS_INV_A = 4, COLS_INV_B = 5, ROWS_INV = 6,
              READ = 7, MEDIANS = 8, CAPACITY = 9, N_STAGES = 10 };
 
-int enqueue_fft_stage(tfft_ctx* c, Slot& s, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
+int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
+    const Slot& s = c->slots[s0];
     const int M = s.PWi / 2;
     const float2 *tw_w, *tw_h;
     int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
     rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
     const ColPlan pl = plan_cols(c, s.PH);
     const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
+    float2 *spec = c->spec(s0), *tmp = c->tmp(s0);
     ColParams cp{};
-    cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M;
+    cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M; cp.img_stride = c->slot_stride;
     switch (stage) {
         case ROWS_FWD: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f};
-            HIPCHK(c, launch_rows_fwd(rgb_in, s.tmp, tw_w, rp, 1, st));
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride};
+            HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
             return TFFT_OK;
         }
         case COLS_FWD_A:
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
-                HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+                HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
-                HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, +1, 3, st));
+                HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, +1, 3 * n, st));
             }
             return TFFT_OK;
         case COLS_FWD_B:
             if (pl.direct) return TFFT_OK;
             // for every k1: length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
             cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
-            HIPCHK(c, launch_cols(s.tmp, s.spec, tw_h, cp, pl.log_n2, +1, 3, st));
+            HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-                HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+                HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
                 cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
-                HIPCHK(c, launch_cols(s.spec, s.tmp, tw_h, cp, pl.log_n2, -1, 3, st));
+                HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             }
             return TFFT_OK;
         case COLS_INV_B:
             if (pl.direct) return TFFT_OK;
             // for every n2: length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
             cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-            HIPCHK(c, launch_cols(s.tmp, s.tmp, tw_h, cp, pl.log_n1, -1, 3, st));
+            HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH))};
-            HIPCHK(c, launch_rows_inv(s.tmp, rgb_out, tw_w, rp, 1, st));
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride};
+            HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
         }
         default: return TFFT_E_INVALID;
     }
 }
 
-// forward: rows (u8 -> tmp) then columns (tmp -> spec)
-int enqueue_forward(tfft_ctx* c, Slot& s, const uint8_t* rgb_dev, hipStream_t st) {
+// forward: rows (u8 -> tmp) then columns (tmp -> spec) for slots [s0, s0+n); images contiguous at rgb_dev
+int enqueue_forward(tfft_ctx* c, int s0, int n, const uint8_t* rgb_dev, hipStream_t st) {
     for (int stage : {ROWS_FWD, COLS_FWD_A, COLS_FWD_B}) {
-        int rc = enqueue_fft_stage(c, s, stage, rgb_dev, nullptr, st);
+        int rc = enqueue_fft_stage(c, s0, n, stage, rgb_dev, nullptr, st);
         if (rc) return rc;
     }
-    s.has_spec = true;
+    for (int i = 0; i < n; i++) c->slots[s0 + i].has_spec = true;
     return TFFT_OK;
 }
 
 // inverse: columns (spec -> tmp, only rows < H kept) then rows (tmp -> u8)
-int enqueue_inverse(tfft_ctx* c, Slot& s, uint8_t* rgb_out_dev, hipStream_t st) {
+int enqueue_inverse(tfft_ctx* c, int s0, int n, uint8_t* rgb_out_dev, hipStream_t st) {
     for (int stage : {COLS_INV_A, COLS_INV_B, ROWS_INV}) {
-        int rc = enqueue_fft_stage(c, s, stage, nullptr, rgb_out_dev, st);
+        int rc = enqueue_fft_stage(c, s0, n, stage, nullptr, rgb_out_dev, st);
         if (rc) return rc;
     }
-    s.has_spec = false;
+    for (int i = 0; i < n; i++) c->slots[s0 + i].has_spec = false;
     return TFFT_OK;
 }
 
-EmbedParams embed_params(const Slot& s, uint64_t n, double alpha, int adaptive, const double med[3], bool has_jitter) {
+EmbedParams embed_params(const tfft_ctx* c, const Slot& s, uint64_t n, double alpha, int adaptive, const double med[3],
+                         bool has_jitter) {
     EmbedParams p{};
     p.n = n; p.PH = s.PH; p.PW = s.PW;
     p.adaptive = adaptive ? 1 : 0;
@@ -201,12 +211,13 @@ EmbedParams embed_params(const Slot& s, uint64_t n, double alpha, int adaptive, 
     p.cos_a = (float)cos(alpha); p.sin_a = (float)sin(alpha);
     p.alpha = alpha;
     for (int i = 0; i < 3; i++) p.med[i] = med ? med[i] : 0.0;
+    p.img_stride = c->slot_stride;
     return p;
 }
 
-CapParams cap_params(const Slot& s, double rmin, double rmax) {
+CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax) {
     CapParams p{};
-    p.PH = s.PH; p.PW = s.PW; p.PWi = s.PWi;
+    p.PH = s.PH; p.PW = s.PW; p.PWi = s.PWi; p.img_stride = c->slot_stride;
     const int mn = s.PH < s.PW ? s.PH : s.PW;
     const double lo = rmin * mn, hi = rmax * mn;        // S:1003
     uint64_t a, b; int empty;
@@ -219,10 +230,17 @@ CapParams cap_params(const Slot& s, double rmin, double rmax) {
     return p;
 }
 
+int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st) {
+    const Slot& s = c->slots[s0];
+    HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
+                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, st));
+    return TFFT_OK;
+}
+
 int ensure_stage(tfft_ctx* c, uint64_t n) {
     if (n <= c->stage_cap) return TFFT_OK;
-    hipStreamSynchronize(c->stream);
-    if (c->stage_bins) { hipFree(c->stage_bins); hipFree(c->stage_bits); hipFree(c->stage_jit); hipFree(c->stage_out); }
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stage_bins) { (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out); }
     c->stage_bins = c->stage_bits = c->stage_jit = c->stage_out = nullptr; c->stage_cap = 0;
     size_t cap = (size_t)n + (size_t)n / 4 + 1024;
     if (dev_alloc(c, &c->stage_bins, cap * sizeof(tfft_bin)) || dev_alloc(c, &c->stage_bits, cap) ||
@@ -232,12 +250,12 @@ int ensure_stage(tfft_ctx* c, uint64_t n) {
     return TFFT_OK;
 }
 
-int check_err_flag(tfft_ctx* c, Slot& s) {
+int check_err_flag(tfft_ctx* c) {
     int flag = 0;
-    HIPCHK(c, hipMemcpyAsync(&flag, s.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&flag, c->err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (flag) {
-        HIPCHK(c, hipMemsetAsync(s.err, 0, sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->err, 0, sizeof(int), c->stream));
         return TFFT_E_BIN_RANGE;
     }
     return TFFT_OK;
@@ -267,7 +285,7 @@ const char* tfft_strerror(int status) {
 }
 
 int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
-    if (!out || max_w < 1 || max_h < 1 || n_slots < 1 || n_slots > 64) return TFFT_E_INVALID;
+    if (!out || max_w < 1 || max_h < 1 || n_slots < 1 || n_slots > 1024) return TFFT_E_INVALID;
     *out = nullptr;
     int pw = next_pow2(max_w), ph = next_pow2(max_h);
     if (pw < 2) pw = 2;
@@ -284,30 +302,26 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
-    int rc = TFFT_OK;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
     c->own_stream = true;
-    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    hipEventCreate(&c->ev_t0); hipEventCreate(&c->ev_t1);
+    (void)hipEventCreate(&c->ev_t0); (void)hipEventCreate(&c->ev_t1);
     c->slots.resize(n_slots);
-    const size_t plane = (size_t)ph * (pw / 2) * sizeof(float2);
-    for (int i = 0; i < n_slots && rc == TFFT_OK; i++) {
-        Slot& s = c->slots[i];
-        rc = dev_alloc(c, (void**)&s.img, (size_t)max_w * max_h * 3 + 16);
-        if (!rc) rc = dev_alloc(c, (void**)&s.spec, 3 * plane);
-        if (!rc) rc = dev_alloc(c, (void**)&s.tmp, 3 * plane);
-        if (!rc) rc = dev_alloc(c, (void**)&s.sel, 3 * sizeof(SelectState));
-        if (!rc) rc = dev_alloc(c, (void**)&s.med, 4 * sizeof(float));
-        if (!rc) rc = dev_alloc(c, (void**)&s.counts, 4 * sizeof(unsigned long long));
-        if (!rc) rc = dev_alloc(c, (void**)&s.usable, sizeof(unsigned long long));
-        if (!rc) rc = dev_alloc(c, (void**)&s.err, sizeof(int));
-        if (!rc) {
-            hipMemset(s.counts, 0, 4 * sizeof(unsigned long long));
-            hipMemset(s.err, 0, sizeof(int));
-            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) rc = TFFT_E_HIP;
-            hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
-        }
-    }
+    const size_t M = (size_t)pw / 2;
+    c->slot_stride = 3 * (size_t)ph * M;
+    c->cand_stride = (size_t)ph * (M + 1);
+    c->img_stride_b = (((size_t)max_w * max_h * 3 + 255) / 256) * 256;
+    const size_t ns = (size_t)n_slots;
+    int rc = dev_alloc(c, (void**)&c->img_pool, ns * c->img_stride_b + 256);
+    if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
+    if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
+    if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
+    if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
+    if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
+    if (!rc) rc = dev_alloc(c, (void**)&c->partial, ns * 3 * TFFT_STAT_MAX_BLOCKS * sizeof(unsigned));
+    if (!rc) rc = dev_alloc(c, (void**)&c->usable, ns * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
+    if (!rc && hipMemset(c->err, 0, sizeof(int)) != hipSuccess) rc = TFFT_E_HIP;
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = TFFT_E_HIP;
     if (rc != TFFT_OK) { tfft_destroy(c); return rc; }
     *out = c;
     return TFFT_OK;
@@ -315,20 +329,15 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
 
 int tfft_destroy(tfft_ctx* c) {
     if (!c) return TFFT_OK;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    for (Slot& s : c->slots) {
-        hipFree(s.img); hipFree(s.spec); hipFree(s.tmp); hipFree(s.sel); hipFree(s.med); hipFree(s.counts);
-        hipFree(s.usable); hipFree(s.err);
-        if (s.stream) hipStreamDestroy(s.stream);
-        if (s.done) hipEventDestroy(s.done);
-    }
-    for (auto& kv : c->tw) hipFree(kv.second);
-    hipFree(c->stage_bins); hipFree(c->stage_bits); hipFree(c->stage_jit); hipFree(c->stage_out);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_t0) hipEventDestroy(c->ev_t0);
-    if (c->ev_t1) hipEventDestroy(c->ev_t1);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err);
+    for (auto& kv : c->tw) (void)hipFree(kv.second);
+    (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TFFT_OK;
 }
@@ -336,7 +345,7 @@ int tfft_destroy(tfft_ctx* c) {
 int tfft_set_stream(tfft_ctx* c, void* hip_stream) {
     if (!c) return TFFT_E_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
     return TFFT_OK;
@@ -344,14 +353,7 @@ int tfft_set_stream(tfft_ctx* c, void* hip_stream) {
 
 int tfft_sync(tfft_ctx* c) {
     if (!c) return TFFT_E_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int rc = TFFT_OK;
-    for (Slot& s : c->slots) {
-        int flag = 0;
-        HIPCHK(c, hipMemcpy(&flag, s.err, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag) { hipMemset(s.err, 0, sizeof(int)); rc = TFFT_E_BIN_RANGE; }
-    }
-    return rc;
+    return check_err_flag(c);
 }
 
 int tfft_last_hip_error(const tfft_ctx* c) { return c ? c->last_hip : 0; }
@@ -364,7 +366,7 @@ int tfft_forward_rgb8_dev(tfft_ctx* c, int slot, const void* rgb_dev, int w, int
     if (rc) return rc;
     if (pw) *pw = s.PW;
     if (ph) *ph = s.PH;
-    return enqueue_forward(c, s, (const uint8_t*)rgb_dev, c->stream);
+    return enqueue_forward(c, slot, 1, (const uint8_t*)rgb_dev, c->stream);
 }
 
 int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, int center, int* pw, int* ph) {
@@ -372,19 +374,19 @@ int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, i
     Slot& s = c->slots[slot];
     int rc = set_geometry(c, s, w, h, center);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(s.img, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->img(slot), rgb, (size_t)w * h * 3, hipMemcpyHostToDevice, c->stream));
     if (pw) *pw = s.PW;
     if (ph) *ph = s.PH;
-    return enqueue_forward(c, s, s.img, c->stream);
+    return enqueue_forward(c, slot, 1, c->img(slot), c->stream);
 }
 
 int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
     if (!slot_ok(c, slot) || !med) return TFFT_E_INVALID;
-    Slot& s = c->slots[slot];
-    if (!s.has_spec) return TFFT_E_STATE;
-    HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, c->stream));
+    if (!c->slots[slot].has_spec) return TFFT_E_STATE;
+    int rc = enqueue_medians(c, slot, 1, c->stream);
+    if (rc) return rc;
     float m[3];
-    HIPCHK(c, hipMemcpyAsync(m, s.med, sizeof m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(m, c->med + 3 * slot, sizeof m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) med[i] = (double)m[i];
     return TFFT_OK;
@@ -394,11 +396,12 @@ int tfft_capacity(tfft_ctx* c, int slot, double rmin, double rmax, const double 
     if (!slot_ok(c, slot) || !thr || !usable) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
     if (!s.has_spec) return TFFT_E_STATE;
-    CapParams p = cap_params(s, rmin, rmax);
+    CapParams p = cap_params(c, s, rmin, rmax);
     for (int i = 0; i < 3; i++) p.thr[i] = thr[i];
-    HIPCHK(c, launch_capacity(s.spec, p, nullptr, s.counts, s.usable, c->stream));
+    HIPCHK(c, launch_capacity(c->spec(slot), p, 1, nullptr, c->partial + (size_t)3 * slot * TFFT_STAT_MAX_BLOCKS,
+                              c->usable + slot, c->stream));
     unsigned long long u = 0;
-    HIPCHK(c, hipMemcpyAsync(&u, s.usable, sizeof u, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&u, c->usable + slot, sizeof u, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *usable = u;
     return TFFT_OK;
@@ -411,8 +414,8 @@ int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
     if (region > s.PH || region > s.PW) return TFFT_E_INVALID;
     const size_t bytes = (size_t)3 * region * region * sizeof(double);
     if (bytes > (size_t)3 * s.PH * (s.PWi / 2) * sizeof(float2)) return TFFT_E_INVALID;
-    double* d = (double*)s.tmp;     // tmp is free between forward and inverse
-    HIPCHK(c, launch_lowfreq(s.spec, s.PH, s.PWi, region, d, c->stream));
+    double* d = (double*)c->tmp(slot);     // tmp is free between forward and inverse
+    HIPCHK(c, launch_lowfreq(c->spec(slot), s.PH, s.PWi, region, d, c->stream));
     HIPCHK(c, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TFFT_OK;
@@ -423,8 +426,8 @@ int tfft_embed_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* bit
     if (!slot_ok(c, slot) || (n && (!bins || !bits)) || (adaptive && !med)) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
     if (!s.has_spec) return TFFT_E_STATE;
-    EmbedParams p = embed_params(s, n, alpha, adaptive, med, jitter != nullptr);
-    HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins, (const uint8_t*)bits, (const float*)jitter, p, s.err, c->stream));
+    EmbedParams p = embed_params(c, s, n, alpha, adaptive, med, jitter != nullptr);
+    HIPCHK(c, launch_embed(c->spec(slot), (const tfft_bin*)bins, (const uint8_t*)bits, (const float*)jitter, p, 1, c->err, c->stream));
     return TFFT_OK;
 }
 
@@ -440,7 +443,7 @@ int tfft_embed_bins(tfft_ctx* c, int slot, const tfft_bin* bins, const uint8_t* 
     if (jitter) HIPCHK(c, hipMemcpyAsync(c->stage_jit, jitter, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     rc = tfft_embed_bins_dev(c, slot, c->stage_bins, c->stage_bits, jitter ? c->stage_jit : nullptr, n, alpha, adaptive, med);
     if (rc) return rc;
-    return check_err_flag(c, c->slots[slot]);
+    return check_err_flag(c);
 }
 
 int tfft_read_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* jitter, uint64_t n, double alpha,
@@ -448,8 +451,8 @@ int tfft_read_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* jitt
     if (!slot_ok(c, slot) || (n && (!bins || !bits_out)) || (adaptive && !med)) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
     if (!s.has_spec) return TFFT_E_STATE;
-    EmbedParams p = embed_params(s, n, alpha, adaptive, med, jitter != nullptr);
-    HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins, (const float*)jitter, p, (uint8_t*)bits_out, s.err, c->stream));
+    EmbedParams p = embed_params(c, s, n, alpha, adaptive, med, jitter != nullptr);
+    HIPCHK(c, launch_read(c->spec(slot), (const tfft_bin*)bins, (const float*)jitter, p, 1, (uint8_t*)bits_out, c->err, c->stream));
     return TFFT_OK;
 }
 
@@ -465,23 +468,22 @@ int tfft_read_bins(tfft_ctx* c, int slot, const tfft_bin* bins, const float* jit
     rc = tfft_read_bins_dev(c, slot, c->stage_bins, jitter ? c->stage_jit : nullptr, n, alpha, adaptive, med, c->stage_out);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(bits_out, c->stage_out, n, hipMemcpyDeviceToHost, c->stream));
-    return check_err_flag(c, c->slots[slot]);
+    return check_err_flag(c);
 }
 
 int tfft_inverse_rgb8_dev(tfft_ctx* c, int slot, void* rgb_out_dev) {
     if (!slot_ok(c, slot) || !rgb_out_dev) return TFFT_E_INVALID;
-    Slot& s = c->slots[slot];
-    if (!s.has_spec) return TFFT_E_STATE;
-    return enqueue_inverse(c, s, (uint8_t*)rgb_out_dev, c->stream);
+    if (!c->slots[slot].has_spec) return TFFT_E_STATE;
+    return enqueue_inverse(c, slot, 1, (uint8_t*)rgb_out_dev, c->stream);
 }
 
 int tfft_inverse_rgb8(tfft_ctx* c, int slot, uint8_t* rgb_out) {
     if (!slot_ok(c, slot) || !rgb_out) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
     if (!s.has_spec) return TFFT_E_STATE;
-    int rc = enqueue_inverse(c, s, s.img, c->stream);
+    int rc = enqueue_inverse(c, slot, 1, c->img(slot), c->stream);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(rgb_out, s.img, (size_t)s.W * s.H * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rgb_out, c->img(slot), (size_t)s.W * s.H * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TFFT_OK;
 }
@@ -493,27 +495,19 @@ int tfft_download_spectrum(tfft_ctx* c, int slot, float* out) {
     const size_t n = (size_t)3 * s.PH * s.PW;
     float2* d = nullptr;
     if (hipMalloc((void**)&d, n * sizeof(float2)) != hipSuccess) return TFFT_E_NOMEM;
-    hipError_t e = launch_export_full(s.spec, s.PH, s.PWi, s.PW, d, c->stream);
+    hipError_t e = launch_export_full(c->spec(slot), s.PH, s.PWi, s.PW, d, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
+    (void)hipFree(d);
     if (e != hipSuccess) { c->last_hip = (int)e; return TFFT_E_HIP; }
     return TFFT_OK;
 }
 
 // ---------------------------------------------------------------- batches
-static int batch_fork(tfft_ctx* c, int used) {
-    if (c->n_slots == 1) return TFFT_OK;
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int i = 0; i < used; i++) HIPCHK(c, hipStreamWaitEvent(c->slots[i].stream, c->ev_fork, 0));
-    return TFFT_OK;
-}
-static int batch_join(tfft_ctx* c, int used) {
-    if (c->n_slots == 1) return TFFT_OK;
-    for (int i = 0; i < used; i++) {
-        HIPCHK(c, hipEventRecord(c->slots[i].done, c->slots[i].stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->slots[i].done, 0));
-    }
+// Images are processed in chunks of n_slots; every stage of a chunk is ONE launch over all its
+// images (grid.z = image), so each kernel sees thousands of workgroups.
+static int batch_geometry(tfft_ctx* c, int g, int w, int h, int center) {
+    for (int i = 0; i < g; i++) { int rc = set_geometry(c, c->slots[i], w, h, center); if (rc) return rc; }
     return TFFT_OK;
 }
 
@@ -521,66 +515,60 @@ int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, 
                          const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
                          void* usable_out_dev, void* rgb_out_dev) {
     if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || (n_bits && (!bins_dev || !bits_dev))) return TFFT_E_INVALID;
-    if (n_images == 0) return TFFT_OK;
-    const int used = n_images < c->n_slots ? n_images : c->n_slots;
-    for (int i = 0; i < used; i++) { int rc = set_geometry(c, c->slots[i], w, h, center); if (rc) return rc; }
-    { const float2* t; int rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
-    int rc = batch_fork(c, used);
-    if (rc) return rc;
     const size_t img_bytes = (size_t)w * h * 3;
-    for (int i = 0; i < n_images; i++) {
-        Slot& s = c->slots[i % c->n_slots];
-        hipStream_t st = (c->n_slots == 1) ? c->stream : s.stream;
-        rc = enqueue_forward(c, s, (const uint8_t*)rgb_dev + (size_t)i * img_bytes, st);
+    for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
+        const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
+        int rc = batch_geometry(c, g, w, h, center);
+        if (rc) return rc;
+        const Slot& s = c->slots[0];
+        rc = enqueue_forward(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, c->stream);
         if (rc) return rc;
         if (usable_out_dev) {      // S:922-923, S:998-1012 on the device, no host round trip
-            HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, st));
-            CapParams p = cap_params(s, rmin, rmax);
+            rc = enqueue_medians(c, 0, g, c->stream);
+            if (rc) return rc;
+            CapParams p = cap_params(c, s, rmin, rmax);
             p.magmin = magmin;
-            HIPCHK(c, launch_capacity(s.spec, p, s.med, s.counts, (unsigned long long*)usable_out_dev + i, st));
+            HIPCHK(c, launch_capacity(c->spec(0), p, g, c->med, c->partial, (unsigned long long*)usable_out_dev + i0, c->stream));
         }
-        EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
-        HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev + (size_t)i * n_bits, nullptr, ep, s.err, st));
-        rc = enqueue_inverse(c, s, (uint8_t*)rgb_out_dev + (size_t)i * img_bytes, st);
+        EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+        HIPCHK(c, launch_embed(c->spec(0), (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev + (size_t)i0 * n_bits, nullptr, ep, g, c->err, c->stream));
+        rc = enqueue_inverse(c, 0, g, (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes, c->stream);
         if (rc) return rc;
     }
-    return batch_join(c, used);
+    return TFFT_OK;
 }
 
 int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
                            uint64_t n_bits, double alpha, void* bits_out_dev) {
     if (!c || n_images < 0 || !rgb_dev || (n_bits && (!bins_dev || !bits_out_dev))) return TFFT_E_INVALID;
-    if (n_images == 0) return TFFT_OK;
-    const int used = n_images < c->n_slots ? n_images : c->n_slots;
-    for (int i = 0; i < used; i++) { int rc = set_geometry(c, c->slots[i], w, h, center); if (rc) return rc; }
-    { const float2* t; int rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
-    int rc = batch_fork(c, used);
-    if (rc) return rc;
     const size_t img_bytes = (size_t)w * h * 3;
-    for (int i = 0; i < n_images; i++) {
-        Slot& s = c->slots[i % c->n_slots];
-        hipStream_t st = (c->n_slots == 1) ? c->stream : s.stream;
-        rc = enqueue_forward(c, s, (const uint8_t*)rgb_dev + (size_t)i * img_bytes, st);
+    for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
+        const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
+        int rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
-        HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins_dev, nullptr, ep, (uint8_t*)bits_out_dev + (size_t)i * n_bits, s.err, st));
+        const Slot& s = c->slots[0];
+        rc = enqueue_forward(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, c->stream);
+        if (rc) return rc;
+        EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+        HIPCHK(c, launch_read(c->spec(0), (const tfft_bin*)bins_dev, nullptr, ep, g, (uint8_t*)bits_out_dev + (size_t)i0 * n_bits, c->err, c->stream));
     }
-    return batch_join(c, used);
+    return TFFT_OK;
 }
 
-int tfft_profile_stage(tfft_ctx* c, int slot, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
+int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
                        const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,
-                       float* ms_per_launch, int* n_launches) {
-    if (!slot_ok(c, slot) || reps < 1 || !ms_per_launch || stage < 0 || stage >= N_STAGES) return TFFT_E_INVALID;
-    Slot& s = c->slots[slot];
+                       float* ms_per_rep, int* n_launches) {
+    if (!c || n_images < 1 || n_images > c->n_slots || reps < 1 || !ms_per_rep || stage < 0 || stage >= N_STAGES) return TFFT_E_INVALID;
+    const Slot& s = c->slots[0];
     if (s.PH == 0) return TFFT_E_STATE;
+    for (int i = 1; i < n_images; i++) c->slots[i] = s;
     const ColPlan pl = plan_cols(c, s.PH);
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if (stage == MEDIANS) launches = 7;
     if (stage == CAPACITY) launches = 2;
     if (n_launches) *n_launches = launches;
-    *ms_per_launch = 0.f;
+    *ms_per_rep = 0.f;
     if (launches == 0) return TFFT_OK;
     { const float2* t; int rc = get_twiddles(c, s.PWi, &t); if (rc) return rc; rc = get_twiddles(c, s.PH, &t); if (rc) return rc; }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
@@ -588,23 +576,23 @@ int tfft_profile_stage(tfft_ctx* c, int slot, int stage, int reps, const void* r
         int rc = TFFT_OK;
         switch (stage) {
             case EMBED: {
-                EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
-                HIPCHK(c, launch_embed(s.spec, (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev, nullptr, ep, s.err, c->stream));
+                EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+                HIPCHK(c, launch_embed(c->spec(0), (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev, nullptr, ep, n_images, c->err, c->stream));
                 break;
             }
             case READ: {
-                EmbedParams ep = embed_params(s, n_bits, alpha, 0, nullptr, false);
-                HIPCHK(c, launch_read(s.spec, (const tfft_bin*)bins_dev, nullptr, ep, (uint8_t*)bits_out_dev, s.err, c->stream));
+                EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+                HIPCHK(c, launch_read(c->spec(0), (const tfft_bin*)bins_dev, nullptr, ep, n_images, (uint8_t*)bits_out_dev, c->err, c->stream));
                 break;
             }
-            case MEDIANS: HIPCHK(c, launch_medians(s.spec, s.PH, s.PWi, s.sel, s.med, c->stream)); break;
+            case MEDIANS: rc = enqueue_medians(c, 0, n_images, c->stream); break;
             case CAPACITY: {
-                CapParams p = cap_params(s, 0.05, 0.45);
+                CapParams p = cap_params(c, s, 0.05, 0.45);
                 p.magmin = 0.01;
-                HIPCHK(c, launch_capacity(s.spec, p, s.med, s.counts, s.usable, c->stream));
+                HIPCHK(c, launch_capacity(c->spec(0), p, n_images, c->med, c->partial, c->usable, c->stream));
                 break;
             }
-            default: rc = enqueue_fft_stage(c, s, stage, (const uint8_t*)rgb_dev, (uint8_t*)rgb_out_dev, c->stream);
+            default: rc = enqueue_fft_stage(c, 0, n_images, stage, (const uint8_t*)rgb_dev, (uint8_t*)rgb_out_dev, c->stream);
         }
         if (rc) return rc;
     }
@@ -612,7 +600,7 @@ int tfft_profile_stage(tfft_ctx* c, int slot, int stage, int reps, const void* r
     HIPCHK(c, hipEventSynchronize(c->ev_t1));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-    *ms_per_launch = ms / (float)reps;
+    *ms_per_rep = ms / (float)reps;
     return TFFT_OK;
 }
 

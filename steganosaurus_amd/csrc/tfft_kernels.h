@@ -12,6 +12,7 @@ struct RowParams {
     int PW, PH;      // padded size (internal PW >= 2)
     int center;      // (-1)^(x+y) pre/post multiply (apply_center)
     float scale;     // inverse only: 1/((PW/2)*PH)
+    size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
 };
 
 struct ColParams {
@@ -24,6 +25,7 @@ struct ColParams {
     int out_rows;      // output rows >= out_rows are not stored
     int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)
     size_t plane_stride;  // float2 elements between planes (PH*M)
+    size_t img_stride;    // float2 elements between images (grid.z = 3*n_images)
 };
 
 struct EmbedParams {
@@ -34,6 +36,7 @@ struct EmbedParams {
     float cos_a, sin_a;
     double alpha;
     double med[3];
+    size_t img_stride;     // float2 elements between images (grid.y = image)
 };
 
 struct CapParams {
@@ -43,13 +46,16 @@ struct CapParams {
     unsigned long long s_lo, s_hi;  // s_lo <= y*y+x*x <= s_hi  <=>  rmin*mn <= hypot(y,x) <= rmax*mn
     double magmin;                  // used with med_dev (batch path)
     double thr[3];                  // used when med_dev == nullptr (tfft_capacity)
+    size_t img_stride;
 };
 
-struct SelectState {
-    unsigned long long hist[2048];
+#define TFFT_STAT_MAX_BLOCKS 512
+
+struct SelectState {        // one per (image, plane)
+    unsigned hist[4096];
     unsigned long long rank;
     unsigned prefix;
-    unsigned pad;
+    unsigned n_cand;
 };
 
 hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
@@ -59,12 +65,13 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s);
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
-                        const EmbedParams& P, int* err, hipStream_t s);
+                        const EmbedParams& P, int n_images, int* err, hipStream_t s);
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
-                       uint8_t* bits_out, int* err, hipStream_t s);
-hipError_t launch_medians(const float2* spec, int PH, int PW, SelectState* st, float* med_out, hipStream_t s);
-hipError_t launch_capacity(const float2* spec, const CapParams& P, const float* med_dev, unsigned long long* counts,
-                           unsigned long long* usable, hipStream_t s);
+                       int n_images, uint8_t* bits_out, int* err, hipStream_t s);
+hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
+                          unsigned* cand, size_t cand_stride, float* med_out, hipStream_t s);
+hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
+                           unsigned* partial, unsigned long long* usable, hipStream_t s);
 hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);
 hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s);
 

@@ -86,7 +86,7 @@ __global__ void k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__
     __syncthreads();
 
     // ---- split into the spectrum of the real row: X[k] = Ev[k] + w^k Od[k], w = exp(+2 pi i/PW)
-    float2* dst = out + (((size_t)img * 3 + plane0 + pb) * P.PH + y) * M;
+    float2* dst = out + (size_t)img * P.img_stride + ((size_t)(plane0 + pb) * P.PH + y) * M;
     for (int k = t; k <= M / 2; k += T) {
         const int k2 = (M - k) & (M - 1);
         const float2 zk = lds[lay.idx(k, pb)], zm = lds[lay.idx(k2, pb)];
@@ -122,7 +122,7 @@ __global__ void k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ 
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
     LayRows lay{LayRows::padded(M)};
 
-    const float2* src = in + (((size_t)img * 3 + plane0 + pb) * P.PH + y) * M;
+    const float2* src = in + (size_t)img * P.img_stride + ((size_t)(plane0 + pb) * P.PH + y) * M;
     for (int k = t; k < M; k += T) lds[lay.idx(k, pb)] = src[k];
     __syncthreads();
 
@@ -192,7 +192,8 @@ __global__ void k_fft_cols(const float2* in, float2* out, const float2* __restri
     const int col = blockIdx.x * C + c;
     const int g = blockIdx.y * blockDim.z + gl;
     const bool active = (col < P.M) && (g < P.G);
-    const size_t plane_off = (size_t)blockIdx.z * P.plane_stride;
+    const int img = blockIdx.z / 3, plane = blockIdx.z - 3 * img;      // grid.z = 3 * n_images
+    const size_t plane_off = (size_t)img * P.img_stride + (size_t)plane * P.plane_stride;
     const float2* src = in + plane_off + col;
     float2* dst = out + plane_off + col;
     float2* lds = reinterpret_cast<float2*>(tfft_smem) + (size_t)gl * L * C;
@@ -250,6 +251,9 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
                         const float* __restrict__ jitter, EmbedParams P, int* __restrict__ err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
+    const int img = blockIdx.y;              // images of a batch share the bin list, not the bits
+    spec += (size_t)img * P.img_stride;
+    bits += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
     const int x = bn.x, y = bn.y, p = bn.plane;
     if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
@@ -278,6 +282,9 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
                        int* __restrict__ err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
+    const int img = blockIdx.y;
+    spec += (size_t)img * P.img_stride;
+    bits_out += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
     const int x = bn.x, y = bn.y, p = bn.plane;
     if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
@@ -308,103 +315,182 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
 }
 
 // ---------------------------------------------------------------------------
-// median_abs S:404-409: exact order statistic (sorted index P/2) of |F| over
-// the full plane, by a 3-pass radix select on the float bit pattern (11+11+10
-// bits).  Stored bins of columns 1..M-1 count twice (bin + mirror), the packed
+// median_abs S:404-409: the exact order statistic (sorted index P/2) of |F| over
+// the full plane, as a 3-level radix select on the float bit pattern:
+//   level 1: 4096-bucket histogram (sign+exponent+4 mantissa bits) of the spectrum
+//   collect: the members of the selected bucket are compacted (low 19 bits + weight)
+//   level 2/3: 1024- and 512-bucket histograms of the compacted candidates
+// Stored bins of columns 1..M-1 count twice (bin + Hermitian mirror); the packed
 // column 0 yields F[.][0] and F[.][M] once each.
-//   grid (blocks, 3)   block 256;   st = SelectState[3]
+// Grids are a few blocks per CU with row loops: thousands of blocks adding to the
+// same few global counters serialise at ~11 ns per atomic.
+//   grid (NB, 3, n_images)   block 256   st[img*3+plane]
 // ---------------------------------------------------------------------------
-template <int PASS>
-__device__ __forceinline__ void hist_add(unsigned* hist, unsigned prefix, float mg, unsigned w) {
-    const unsigned b = __float_as_uint(mg);
-    if (PASS == 0) atomicAdd(&hist[b >> 21], w);
-    else if (PASS == 1) { if ((b >> 21) == prefix) atomicAdd(&hist[(b >> 10) & 2047], w); }
-    else { if ((b >> 10) == prefix) atomicAdd(&hist[b & 1023], w); }
-}
-template <int PASS>
-__global__ void k_mag_hist(const float2* __restrict__ spec, int PH, int M, SelectState* __restrict__ st) {
-    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 2048 counters (dynamic LDS)
-    const int plane = blockIdx.y;
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const float2* pl = spec + (size_t)plane * PH * M;
-    const unsigned prefix = st[plane].prefix;
-    const size_t n = (size_t)PH * M;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(e / M), x = (int)(e - (size_t)y * M);
-        if (x == 0) {
-            float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
-            hist_add<PASS>(hist, prefix, mag_of(f0), 1); hist_add<PASS>(hist, prefix, mag_of(fm), 1);
-        } else {
-            hist_add<PASS>(hist, prefix, mag_of(pl[e]), 2);
-        }
+__device__ __forceinline__ SelectState* sel_of(SelectState* st) { return st + (size_t)blockIdx.z * 3 + blockIdx.y; }
+
+template <class F>
+__device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f) {
+    if (x == 0) {
+        float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
+        f(__float_as_uint(mag_of(f0)), 1u); f(__float_as_uint(mag_of(fm)), 1u);
+    } else {
+        f(__float_as_uint(mag_of(pl[(size_t)y * M + x])), 2u);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x)
-        if (hist[i]) atomicAdd(&st[plane].hist[i], (unsigned long long)hist[i]);
 }
-// one block per plane: pick the bucket holding the wanted rank, zero the histogram
-template <int PASS>
+
+__global__ void k_hist_spec(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
+                            SelectState* __restrict__ st) {
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 4096 counters
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
+    for (int y = blockIdx.x; y < PH; y += gridDim.x)
+        for (int x = threadIdx.x; x < M; x += blockDim.x)
+            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); });
+    __syncthreads();
+    SelectState* s = sel_of(st);
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// One block of 256 threads per (image, plane): find the bucket that holds rank s->rank among
+// NB buckets (three-level sum so that no thread walks more than 16 LDS words), clear the
+// histogram for the next level, update prefix/rank.
+template <int LEVEL>
 __global__ void k_select(SelectState* __restrict__ st, float* __restrict__ med_out) {
-    const int plane = blockIdx.x;
-    SelectState& s = st[plane];
-    if (threadIdx.x == 0) {
-        unsigned long long cum = 0, rank = s.rank;
-        const int nb = (PASS == 2) ? 1024 : 2048;
-        int sel = nb - 1;
-        for (int i = 0; i < nb; i++) {
-            if (cum + s.hist[i] > rank) { sel = i; break; }
-            cum += s.hist[i];
-        }
-        s.rank = rank - cum;
-        s.prefix = (PASS == 0) ? (unsigned)sel : (PASS == 1) ? ((s.prefix << 11) | (unsigned)sel)
-                                                            : ((s.prefix << 10) | (unsigned)sel);
-        if (PASS == 2) med_out[plane] = __uint_as_float(s.prefix);
+    constexpr int NB = (LEVEL == 1) ? 4096 : (LEVEL == 2) ? 1024 : 512;
+    constexpr int SHIFT = (LEVEL == 1) ? 0 : (LEVEL == 2) ? 10 : 9;
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem);          // NB + 256 + 16 words
+    unsigned* p1 = h + 4096;
+    unsigned* p2 = p1 + 256;
+    SelectState* s = st + blockIdx.x;
+    const int t = threadIdx.x;
+    for (int i = t; i < 4096; i += 256) { h[i] = (i < NB) ? s->hist[i] : 0u; }
+    __syncthreads();
+    { unsigned a = 0; for (int i = 0; i < 16; i++) a += h[t * 16 + i]; p1[t] = a; }
+    __syncthreads();
+    if (t < 16) { unsigned a = 0; for (int i = 0; i < 16; i++) a += p1[t * 16 + i]; p2[t] = a; }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long rank = s->rank, cum = 0;
+        int g2 = 15; for (int i = 0; i < 16; i++) { if (cum + p2[i] > rank) { g2 = i; break; } cum += p2[i]; }
+        int g1 = g2 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + p1[g2 * 16 + i] > rank) { g1 = g2 * 16 + i; break; } cum += p1[g2 * 16 + i]; }
+        int b = g1 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + h[g1 * 16 + i] > rank) { b = g1 * 16 + i; break; } cum += h[g1 * 16 + i]; }
+        if (b >= NB) b = NB - 1;
+        s->rank = rank - cum;
+        s->prefix = (LEVEL == 1) ? (unsigned)b : ((s->prefix << SHIFT) | (unsigned)b);
+        if (LEVEL == 3) med_out[blockIdx.x] = __uint_as_float(s->prefix);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.hist[i] = 0;
+    for (int i = t; i < 4096; i += 256) s->hist[i] = 0;
 }
+
 __global__ void k_select_init(SelectState* __restrict__ st, unsigned long long rank) {
-    SelectState& s = st[blockIdx.x];
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s.hist[i] = 0;
-    if (threadIdx.x == 0) { s.rank = rank; s.prefix = 0; }
+    SelectState* s = st + blockIdx.x;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s->hist[i] = 0;
+    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; }
+}
+
+// Compaction of the selected level-1 bucket: candidates are staged in LDS (<= 2 per element of
+// a 1024-element chunk), one global atomic per chunk reserves the output range.  Each candidate
+// is (low 19 bits of the magnitude) | (weight 2 ? 1<<31 : 0).  Also accumulates the level-2
+// histogram of what it appends.
+__global__ void k_collect(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
+                          SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
+    unsigned* buf = hist + 1024;                                  // 2048 staged candidates
+    unsigned* cnt = buf + 2048;                                   // [0] staged count, [1] global base
+    SelectState* s = sel_of(st);
+    const unsigned prefix = s->prefix;
+    unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) cnt[0] = 0;
+    __syncthreads();
+    for (int y = blockIdx.x; y < PH; y += gridDim.x) {
+        for (int x0 = 0; x0 < M; x0 += 1024) {
+            for (int x = x0 + threadIdx.x; x < M && x < x0 + 1024; x += blockDim.x)
+                for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
+                    if ((b >> 19) == prefix) {
+                        buf[atomicAdd(&cnt[0], 1u)] = (b & 0x7FFFFu) | (w == 2u ? 0x80000000u : 0u);
+                        atomicAdd(&hist[(b >> 9) & 1023u], w);
+                    }
+                });
+            __syncthreads();
+            const unsigned n = cnt[0];
+            if (n) {
+                if (threadIdx.x == 0) cnt[1] = atomicAdd(&s->n_cand, n);
+                __syncthreads();
+                const unsigned base = cnt[1];
+                for (unsigned i = threadIdx.x; i < n; i += blockDim.x) out[base + i] = buf[i];
+                __syncthreads();
+                if (threadIdx.x == 0) cnt[0] = 0;
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// level-3 histogram over the compacted candidates (those in the level-2 bucket)
+__global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 512 counters
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    SelectState* s = sel_of(st);
+    const unsigned want = s->prefix & 1023u, n = s->n_cand;
+    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned c = in[i];
+        if (((c >> 9) & 1023u) == want) atomicAdd(&hist[c & 511u], (c >> 31) ? 2u : 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
 }
 
 // ---------------------------------------------------------------------------
 // capacity count_plane S:998-1008 over the bounding box of the annulus.
 // The radius test is done on exact integers: s_lo <= y*y+x*x <= s_hi, with the
-// bounds derived on the host from the reference's double comparison.
-//   grid (ceil(bw*bh/256), 3)    thr: magmin*median per plane (double)
+// bounds derived on the host from the reference's double comparison.  Each block
+// walks rows of the box and writes ONE partial count (no global atomics).
+//   grid (NB, 3, n_images)  block 256   partial[(img*3+plane)*NB + block]
 // ---------------------------------------------------------------------------
 __global__ void k_capacity(const float2* __restrict__ spec, CapParams P, const float* __restrict__ med_dev,
-                           unsigned long long* __restrict__ counts) {
-    unsigned& blk = *reinterpret_cast<unsigned*>(tfft_smem);
-    if (threadIdx.x == 0) blk = 0;
+                           unsigned* __restrict__ partial) {
+    unsigned* blk = reinterpret_cast<unsigned*>(tfft_smem);
+    if (threadIdx.x == 0) blk[0] = 0;
     __syncthreads();
-    const int plane = blockIdx.y;
-    const double thr = med_dev ? P.magmin * (double)med_dev[plane] : P.thr[plane];
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (size_t)P.bw * P.bh) {
-        const int y = (int)(e / P.bw), x = (int)(e - (size_t)y * P.bw);
-        const unsigned long long s = (unsigned long long)y * y + (unsigned long long)x * x;
-        const bool axis = (y == 0 || x == 0 || 2 * y == P.PH || 2 * x == P.PW);
-        if (!axis && s >= P.s_lo && s <= P.s_hi) {
-            const float2 v = full_bin(spec + (size_t)plane * P.PH * (P.PWi >> 1), y, x, P.PH, P.PWi);
-            if (!((double)mag_of(v) < thr)) atomicAdd(&blk, 1u);
+    const int plane = blockIdx.y, img = blockIdx.z;
+    const double thr = med_dev ? P.magmin * (double)med_dev[img * 3 + plane] : P.thr[plane];
+    const float2* pl = spec + (size_t)img * P.img_stride + (size_t)plane * P.PH * (P.PWi >> 1);
+    unsigned mine = 0;
+    for (int y = blockIdx.x; y < P.bh; y += gridDim.x) {
+        if (y == 0 || 2 * y == P.PH) continue;
+        const unsigned long long yy = (unsigned long long)y * y;
+        for (int x = threadIdx.x; x < P.bw; x += blockDim.x) {
+            const unsigned long long s = yy + (unsigned long long)x * x;
+            if (x == 0 || 2 * x == P.PW || s < P.s_lo || s > P.s_hi) continue;
+            const float2 v = full_bin(pl, y, x, P.PH, P.PWi);
+            if (!((double)mag_of(v) < thr)) mine++;
         }
     }
+    if (mine) atomicAdd(&blk[0], mine);
     __syncthreads();
-    if (threadIdx.x == 0 && blk) atomicAdd(&counts[plane], (unsigned long long)blk);
+    if (threadIdx.x == 0) partial[((size_t)img * 3 + plane) * gridDim.x + blockIdx.x] = blk[0];
 }
-// usable = sum_p floor(c_p/2); also resets the counters for the next image
-__global__ void k_capacity_final(unsigned long long* __restrict__ counts, unsigned long long* __restrict__ usable) {
-    if (threadIdx.x == 0) {
-        // read-and-reset with atomics: a plain load followed by a plain store of 0 was compiled to an
-        // un-waited scalar load racing the vector store (SMEM and VMEM are not ordered with each other)
-        const unsigned long long c0 = atomicExch(&counts[0], 0ull), c1 = atomicExch(&counts[1], 0ull),
-                                 c2 = atomicExch(&counts[2], 0ull);
-        *usable = c0 / 2 + c1 / 2 + c2 / 2;
+// usable[img] = sum_p floor(c_p/2): one thread block per image sums the partial counts
+__global__ void k_capacity_final(const unsigned* __restrict__ partial, int nb, unsigned long long* __restrict__ usable) {
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3]
+    const int img = blockIdx.x;
+    if (threadIdx.x < 3) {
+        unsigned long long a = 0;
+        for (int i = 0; i < nb; i++) a += partial[((size_t)img * 3 + threadIdx.x) * nb + i];
+        c[threadIdx.x] = a;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) usable[img] = c[0] / 2 + c[1] / 2 + c[2] / 2;
 }
 
 // ---------------------------------------------------------------------------
@@ -490,7 +576,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
     const size_t lds = (size_t)gpb * L * C * sizeof(float2);
-    dim3 grid((P.M + C - 1) / C, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);
+    dim3 grid((P.M + C - 1) / C, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -511,45 +597,51 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
 }
 
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
-                        const EmbedParams& P, int* err, hipStream_t s) {
-    if (P.n == 0) return hipSuccess;
+                        const EmbedParams& P, int n_images, int* err, hipStream_t s) {
+    if (P.n == 0 || n_images == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P.n + 255) / 256);
-    hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), 0, s, spec, bins, bits, jitter, P, err);
+    hipLaunchKernelGGL(k_embed, dim3(blocks, n_images), dim3(256), 0, s, spec, bins, bits, jitter, P, err);
     return hipGetLastError();
 }
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
-                       uint8_t* bits_out, int* err, hipStream_t s) {
-    if (P.n == 0) return hipSuccess;
+                       int n_images, uint8_t* bits_out, int* err, hipStream_t s) {
+    if (P.n == 0 || n_images == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((P.n + 255) / 256);
-    hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, s, spec, bins, jitter, P, bits_out, err);
+    hipLaunchKernelGGL(k_read, dim3(blocks, n_images), dim3(256), 0, s, spec, bins, jitter, P, bits_out, err);
     return hipGetLastError();
 }
 
-hipError_t launch_medians(const float2* spec, int PH, int PW, SelectState* st, float* med_out, hipStream_t s) {
+static unsigned stat_blocks(int rows, int n_images) {
+    // about 4 blocks per CU over the whole launch (256 CUs), never more blocks than rows
+    int nb = (1024 + 3 * n_images - 1) / (3 * n_images);
+    if (nb < 1) nb = 1;
+    if (nb > rows) nb = rows;
+    if (nb > TFFT_STAT_MAX_BLOCKS) nb = TFFT_STAT_MAX_BLOCKS;
+    return (unsigned)nb;
+}
+
+hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
+                          unsigned* cand, size_t cand_stride, float* med_out, hipStream_t s) {
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
-    const size_t n = (size_t)PH * M;
-    unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_select_init, dim3(3), dim3(256), 0, s, st, rank);
-    hipLaunchKernelGGL(k_mag_hist<0>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
-    hipLaunchKernelGGL(k_select<0>, dim3(3), dim3(256), 0, s, st, med_out);
-    hipLaunchKernelGGL(k_mag_hist<1>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
-    hipLaunchKernelGGL(k_select<1>, dim3(3), dim3(256), 0, s, st, med_out);
-    hipLaunchKernelGGL(k_mag_hist<2>, dim3(blocks, 3), dim3(256), 2048 * sizeof(unsigned), s, spec, PH, M, st);
-    hipLaunchKernelGGL(k_select<2>, dim3(3), dim3(256), 0, s, st, med_out);
+    const unsigned nb = stat_blocks(PH, n_images);
+    const unsigned sel_lds = (4096 + 256 + 16) * sizeof(unsigned);
+    hipLaunchKernelGGL(k_select_init, dim3(3 * n_images), dim3(256), 0, s, st, rank);
+    hipLaunchKernelGGL(k_hist_spec, dim3(nb, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st);
+    hipLaunchKernelGGL(k_select<1>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_collect, dim3(nb, 3, n_images), dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M,
+                       img_stride, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select<2>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_hist_cand, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select<3>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
     return hipGetLastError();
 }
 
-hipError_t launch_capacity(const float2* spec, const CapParams& P, const float* med_dev, unsigned long long* counts,
-                           unsigned long long* usable, hipStream_t s) {
-    const size_t n = (size_t)P.bw * P.bh;
-    if (n) {
-        const unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_capacity, dim3(blocks, 3), dim3(256), 16, s, spec, P, med_dev, counts);
-    }
-    hipLaunchKernelGGL(k_capacity_final, dim3(1), dim3(64), 0, s, counts, usable);
+hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
+                           unsigned* partial, unsigned long long* usable, hipStream_t s) {
+    unsigned nb = stat_blocks(P.bh > 0 ? P.bh : 1, n_images);
+    hipLaunchKernelGGL(k_capacity, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
+    hipLaunchKernelGGL(k_capacity_final, dim3(n_images), dim3(64), 32, s, partial, (int)nb, usable);
     return hipGetLastError();
 }
 

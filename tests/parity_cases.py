@@ -22,7 +22,8 @@ def spec_errors(got, want):
     """How "FFT coefficients within 1e-4 relative" (north_star) is measured for an fp32
     transform checked against the fp64 reference.  Returns
       nrm : ||got-want|| / ||want||                       (normwise relative error)
-      mx  : max |got-want| / rms(|want|)                  (worst absolute error, in units of the rms)
+      mx  : max over ALL coefficients of |got-want| / (1e-4*|want| + 1e-5*rms(|want|))
+            (<= 1 means every coefficient is within rtol 1e-4 plus an absolute floor of 1e-5 rms)
       rel : max |got-want| / |want| over coefficients with |want| >= 0.1 * rms
     A per-coefficient relative figure is only meaningful for coefficients that are not
     far below the spectrum's rms: an fp32 FFT has an absolute rounding floor of a few
@@ -34,13 +35,13 @@ def spec_errors(got, want):
     rms = max(1e-300, np.sqrt(np.mean(np.abs(want) ** 2)))
     big = np.abs(want) >= 0.1 * rms
     rel = (err[big] / np.abs(want)[big]).max() if big.any() else 0.0
-    return nrm, err.max() / rms, rel
+    return nrm, (err / (1e-4 * np.abs(want) + 1e-5 * rms)).max(), rel
 
 
 def assert_spectrum_close(got, want, tag=""):
     nrm, mx, rel = spec_errors(got, want)
     assert nrm < 2e-6, (tag, "normwise", nrm)            # 50x inside the 1e-4 tolerance
-    assert mx < 1e-5, (tag, "max abs / rms", mx)
+    assert mx <= 1.0, (tag, "rtol 1e-4 + atol 1e-5*rms", mx)
     assert rel < 1e-4, (tag, "per-coefficient", rel)     # the north_star tolerance
 
 

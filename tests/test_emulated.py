@@ -61,3 +61,33 @@ def test_embed_mirror_half(emu, orc):
 
 def test_error_paths(emu):
     PC.check_error_paths(emu)
+
+
+def test_batch_matches_single(emu, orc):
+    """tfft_*_batch_dev over chunks of slots == the single-image calls (emulated: device pointers are host arrays)."""
+    from steganosaurus_amd.synth import cover_rgb, n_stream_bits
+    w, h, nimg = 40, 24, 5
+    n = 120
+    imgs = np.stack([cover_rgb(w, h, i) for i in range(nimg)])
+    bits = np.random.default_rng(2).integers(0, 2, (nimg, n)).astype(np.uint8)
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, lib=emu).next(n)
+    out = np.zeros_like(imgs)
+    usable = np.zeros(nimg, np.uint64)
+    raw = np.zeros((nimg, n), np.uint8)
+    ctx = B.Context(w, h, slots=3, lib=emu)
+    ctx.embed_batch_dev(nimg, imgs.ctypes.data, w, h, bins.ctypes.data, bits.ctypes.data, n, out.ctypes.data,
+                        usable_ptr=usable.ctypes.data)
+    ctx.extract_batch_dev(nimg, out.ctypes.data, w, h, bins.ctypes.data, n, raw.ctypes.data)
+    ctx.sync()
+    one = B.Context(w, h, lib=emu)
+    for i in range(nimg):
+        one.forward_rgb8(imgs[i])
+        med = one.medians()
+        assert one.capacity(0.01 * med) == int(usable[i])
+        one.embed_bins(bins, bits[i])
+        st = one.inverse_rgb8(w, h)
+        assert np.array_equal(st, out[i]), i
+        one.forward_rgb8(st)
+        assert np.array_equal(one.read_bins(bins), raw[i]), i
+    one.close(); ctx.close()
