@@ -104,13 +104,13 @@ struct FftPasses {
             for (int r = 0; r < R; r++) v[r] = u[q + r * Q];
             const int i = t + q * T;
             const int k = i & (P - 1);
-            if constexpr (P > 1) {   // inter-pass twiddles exp(SIGN*2*pi*i*r*k/(P*R)), powers by a balanced product tree
-                float2 w[R];
-                w[1] = twload<SIGN>(tw, k * (N / (P * R)) * tws);
+            if constexpr (P > 1) {
+                // inter-pass twiddles exp(SIGN*2*pi*i*r*k/(P*R)), each read from the table (r*k < P*R, so
+                // the index stays below N).  Powers of w^k by repeated products would carry r times the
+                // table's rounding error into the large low-frequency partial sums of DC-heavy images.
+                const int base = k * (N / (P * R)) * tws;
 #pragma unroll
-                for (int r = 2; r < R; r++) w[r] = cmul(w[r / 2], w[(r + 1) / 2]);
-#pragma unroll
-                for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+                for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
             }
             DftReg<R, SIGN, 0, R>::run(v);
             if constexpr (LAST) {

@@ -36,7 +36,7 @@ __device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, 
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)   T = M/E
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
+__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
@@ -111,7 +111,7 @@ __global__ void k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
+__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
@@ -184,8 +184,9 @@ __global__ void k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ 
 // The column loop of fft2d S:362-365.
 //   grid (ceil(M/16), ceil(G/GPB), n_planes)   block (16, T, GPB)
 // ---------------------------------------------------------------------------
+constexpr int cols_threads(int logl) { return imax(256, 16 * ((1 << logl) / elems_for(1 << logl))); }
 template <int LOGL, int SIGN>
-__global__ void k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
+__global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
