@@ -164,6 +164,7 @@ int tfft_walk_jitter(const uint8_t keys_rgb[96], const tfft_bin* bins, uint64_t 
  * Device-side timing of whatever was enqueued between the two calls on the
  * context's stream (hipEvent pair on that stream). */
 int tfft_timer_begin(tfft_ctx* ctx);
+int tfft_timer_end(tfft_ctx* ctx, float* ms);
 /* Per-kernel timing for the roofline report: enqueue stage `stage` of the
  * batched pipeline over slots [0, n_images) `reps` times on the context's stream
  * between two HIP events; returns the mean time of ONE repetition (ms) and how
