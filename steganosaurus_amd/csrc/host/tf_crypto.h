@@ -43,9 +43,10 @@ bool aead_open(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* aa
 // (steganosaur.cpp:192-270) assembles the final tag from its 26-bit limbs in 64-bit
 // arithmetic WITHOUT truncating (h0 | h1<<26) etc. to 32 bits before propagating carries
 // (S:261-264), so limb bits are counted twice and the tag is NOT the RFC 8439 tag.  Stego
-// images are only interoperable with the reference if that exact value is reproduced, so
-// the stream framing uses these two; key wrapping (which the reference does with its
-// standards-conforming library AEAD, crypto/chacha20poly1305.cpp) uses aead_seal/aead_open.
+// images are only interoperable with the reference if that exact value is reproduced.  The
+// reference's library AEAD (crypto/chacha20poly1305.cpp:100-190, used for key wrapping) has the
+// same tag assembly, so the CLI uses these two everywhere; aead_seal/aead_open above are the
+// RFC-conformant primitive (tested against the RFC 8439 vector) and are not used on the wire.
 void aead_seal_turtle(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* aad, size_t alen, const uint8_t* pt,
                       size_t len, uint8_t* ct_out, uint8_t tag[16]);
 bool aead_open_turtle(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* aad, size_t alen, const uint8_t* ct,

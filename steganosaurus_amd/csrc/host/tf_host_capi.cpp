@@ -21,6 +21,9 @@ void tfh_aead_seal(const uint8_t key[32], const uint8_t nonce[12], const uint8_t
 int tfh_aead_open(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* aad, size_t al, const uint8_t* ct, size_t n,
                   const uint8_t tag[16], uint8_t* pt) { return aead_open(key, nonce, aad, al, ct, n, tag, pt) ? 1 : 0; }
 
+int tfh_aead_open_turtle(const uint8_t key[32], const uint8_t nonce[12], const uint8_t* aad, size_t al, const uint8_t* ct, size_t n,
+                         const uint8_t tag[16], uint8_t* pt) { return aead_open_turtle(key, nonce, aad, al, ct, n, tag, pt) ? 1 : 0; }
+
 // Rep-3(header) || Rep-7(ct || tag) for a passphrase and a caller-fixed salt; returns the bit count (0 if cap is too small)
 uint64_t tfh_frame_bits(const char* pass, const uint8_t salt16[16], uint32_t iters, const uint8_t* secret, uint32_t slen,
                         uint8_t* bits_out, uint64_t cap) {

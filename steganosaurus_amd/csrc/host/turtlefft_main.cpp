@@ -107,7 +107,7 @@ bool decode_or_unwrap_key(const std::string& key_data, const std::string& unwrap
         if (unwrap_pass.empty()) { fprintf(stderr, "Key is wrapped but no unwrap passphrase provided\n"); return false; }
         uint8_t derived[44];
         pbkdf2_hmac_sha256((const uint8_t*)unwrap_pass.data(), unwrap_pass.size(), d.data() + 4, 16, iters, derived, 44);
-        const bool ok = aead_open(derived, d.data() + 20, nullptr, 0, d.data() + 32, 32, d.data() + 64, key_out.data());
+        const bool ok = aead_open_turtle(derived, d.data() + 20, nullptr, 0, d.data() + 32, 32, d.data() + 64, key_out.data());
         secure_zero(derived, sizeof derived);
         return ok;
     }
@@ -272,7 +272,7 @@ void do_gen_key(const Args& A) {    // S:1315-1416
             blob.insert(blob.end(), salt, salt + 16);
             blob.insert(blob.end(), derived + 32, derived + 44);
             blob.resize(80);
-            aead_seal(derived, derived + 32, nullptr, 0, master.data(), 32, &blob[32], &blob[64]);
+            aead_seal_turtle(derived, derived + 32, nullptr, 0, master.data(), 32, &blob[32], &blob[64]);
             secure_zero(derived, sizeof derived);
             text = base64_encode(blob.data(), blob.size()) + "\n";
             printf("  Wrapped with passphrase and exported to: %s\n", A.keyOutPath.c_str());

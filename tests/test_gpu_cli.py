@@ -44,7 +44,7 @@ def test_ours_roundtrip_and_messages(covers):
     r = run(CLI, "extract", "--in", st, "--pass", "wrong", *IT)
     assert (r.returncode, r.stderr) == (1, "Magic not found.\n")
     r = run(CLI, "embed", "--in", covers["grad256"], "--out", st, "--secret", "x" * 4000, "--pass", "p", *IT)
-    assert r.returncode == 1 and r.stderr.startswith("Message too large. Need 225792 bits (after ECC), capacity ~")
+    assert r.returncode == 1 and r.stderr.startswith("Message too large. Need 225808 bits (after ECC), capacity ~")
 
 
 @pytest.mark.skipif(not have_ref(), reason="reference CLI not present")
