@@ -59,6 +59,8 @@ struct tfft_ctx {
     size_t stage_cap = 0;
     int cols_direct_max_log = 9;          // PH <= 512: one column pass; taller: two-step N1 x N2
     int cols_force_log_n1 = -1;
+    int cols_tiles_per_block = 8;
+    int rows_per_block = 8;
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
     float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
@@ -137,9 +139,10 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     float2 *spec = c->spec(s0), *tmp = c->tmp(s0);
     ColParams cp{};
     cp.M = M; cp.PH = s.PH; cp.plane_stride = (size_t)s.PH * M; cp.img_stride = c->slot_stride;
+    cp.tiles_per_block = c->cols_tiles_per_block;
     switch (stage) {
         case ROWS_FWD: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->rows_per_block, n};
             HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
             return TFFT_OK;
         }
@@ -174,7 +177,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->rows_per_block, n};
             HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
         }
@@ -301,6 +304,8 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->device = device; c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots;
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
+    if (const char* e = getenv("TFFT_ROWS_PER_BLOCK")) c->rows_per_block = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
     c->own_stream = true;

@@ -83,19 +83,70 @@ __device__ __forceinline__ float2 twload(const float2* __restrict__ tw, int j) {
     return SIGN > 0 ? w : cconj(w);
 }
 
+// Synchronisation between the scatter and the gather of an LDS exchange.
+//   BlockSync: the sequence is spread over several waves -> workgroup barrier.
+//   WaveSync : the whole sequence lives in ONE wave (N/E == 64).  DS instructions of a wave execute
+//              in issue order, so only the compiler has to be kept from reordering / caching: no
+//              s_barrier, waves of the workgroup run their passes independently.
+struct BlockSync { static __device__ __forceinline__ void sync() { __syncthreads(); } };
+struct WaveSync {
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// Inter-pass twiddles.  Their table indices depend only on the thread's position (never on data), so a
+// kernel fetches ALL of them into registers right after it has issued its data loads: the L2 latency
+// of the table reads then overlaps the HBM latency of the data instead of stalling every pass.
+template <int N, int E, int P>
+struct TwCount {
+    static constexpr int R = imin(E, N / P);
+    static constexpr int mine = (P > 1) ? (E / R) * (R - 1) : 0;
+    static constexpr int value = mine + TwCount<N, E, P * R>::value;
+};
+template <int N, int E>
+struct TwCount<N, E, N> { static constexpr int value = 0; };
+template <int N, int E>
+constexpr int tw_regs() { return imax(1, TwCount<N, E, 1>::value); }
+
+template <int N, int E, int SIGN, int P, int OFF, int TOT>
+struct TwLoad {
+    static constexpr int R = imin(E, N / P);
+    static constexpr int T = N / E, Q = E / R;
+    static __device__ __forceinline__ void run(float2 (&W)[TOT], int t, const float2* __restrict__ tw, int tws) {
+        if constexpr (P > 1) {
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int k = (t + q * T) & (P - 1);
+                const int base = k * (N / (P * R)) * tws;       // exp(SIGN*2*pi*i*r*k/(P*R)) = tw[r*base], r*k < P*R
+#pragma unroll
+                for (int r = 1; r < R; r++) W[OFF + q * (R - 1) + r - 1] = twload<SIGN>(tw, r * base);
+            }
+        }
+        if constexpr (P * R < N) TwLoad<N, E, SIGN, P * R, OFF + ((P > 1) ? Q * (R - 1) : 0), TOT>::run(W, t, tw, tws);
+    }
+};
+template <int N, int E, int SIGN, int TOT>
+__device__ __forceinline__ void fft_prefetch_twiddles(float2 (&W)[TOT], int t, const float2* __restrict__ tw, int tws) {
+    // tw[j*tws] = exp(+2*pi*i*j/N): one table per image dimension serves every sub-length
+    if constexpr (N > 1) TwLoad<N, E, SIGN, 1, 0, TOT>::run(W, t, tw, tws);
+}
+
 // All radix passes of a length-N FFT for one thread.
 //   u[m] holds x[t + m*T] on entry and X[t + m*T] on exit (T = N/E).
-//   lds/lay: exchange buffer (N elements per sequence);  tw: table for size N.
+//   lds/lay: exchange buffer (N elements per sequence);  W: twiddles from fft_prefetch_twiddles.
 //   Every thread of the workgroup must call this (it contains barriers), also
 //   threads whose sequence is out of range.
-template <int N, int E, int SIGN, int P, class Lay>
+template <int N, int E, int SIGN, int P, int OFF, int TOT, class Lay, class Sync>
 struct FftPasses {
     static constexpr int R = imin(E, N / P);        // radix of this pass
     static constexpr bool LAST = (P * R == N);
     static constexpr int T = N / E;
     static constexpr int Q = E / R;                  // butterflies per thread
     static __device__ __forceinline__ void run(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
-                                               const float2* __restrict__ tw, int tws) {
+                                               const float2 (&W)[TOT]) {
         float2 o[E];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
@@ -105,12 +156,8 @@ struct FftPasses {
             const int i = t + q * T;
             const int k = i & (P - 1);
             if constexpr (P > 1) {
-                // inter-pass twiddles exp(SIGN*2*pi*i*r*k/(P*R)), each read from the table (r*k < P*R, so
-                // the index stays below N).  Powers of w^k by repeated products would carry r times the
-                // table's rounding error into the large low-frequency partial sums of DC-heavy images.
-                const int base = k * (N / (P * R)) * tws;
 #pragma unroll
-                for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
+                for (int r = 1; r < R; r++) v[r] = cmul(v[r], W[OFF + q * (R - 1) + r - 1]);
             }
             DftReg<R, SIGN, 0, R>::run(v);
             if constexpr (LAST) {
@@ -126,20 +173,19 @@ struct FftPasses {
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = o[m];
         } else {
-            __syncthreads();
+            Sync::sync();
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, b)];
-            __syncthreads();
-            FftPasses<N, E, SIGN, P * R, Lay>::run(u, lds, lay, t, b, tw, tws);
+            Sync::sync();
+            FftPasses<N, E, SIGN, P * R, OFF + ((P > 1) ? Q * (R - 1) : 0), TOT, Lay, Sync>::run(u, lds, lay, t, b, W);
         }
     }
 };
 
-template <int N, int E, int SIGN, class Lay>
+template <int N, int E, int SIGN, class Sync = BlockSync, class Lay, int TOT>
 __device__ __forceinline__ void fft_block(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
-                                          const float2* __restrict__ tw, int tws) {
-    // tw[j*tws] = exp(+2*pi*i*j/N): one table per image dimension serves every sub-length
-    if constexpr (N > 1) FftPasses<N, E, SIGN, 1, Lay>::run(u, lds, lay, t, b, tw, tws);
+                                          const float2 (&W)[TOT]) {
+    if constexpr (N > 1) FftPasses<N, E, SIGN, 1, 0, TOT, Lay, Sync>::run(u, lds, lay, t, b, W);
 }
 
 // elements per thread for a length-N transform

@@ -13,6 +13,8 @@ struct RowParams {
     int center;      // (-1)^(x+y) pre/post multiply (apply_center)
     float scale;     // inverse only: 1/((PW/2)*PH)
     size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
+    int rows_per_block;  // consecutive rows walked by one workgroup
+    int n_images;        // images in this launch (extent of the u8 buffer)
 };
 
 struct ColParams {
@@ -24,6 +26,7 @@ struct ColParams {
     int in_rows;       // input rows >= in_rows are zero (not loaded)
     int out_rows;      // output rows >= out_rows are not stored
     int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)
+    int tiles_per_block;  // adjacent 16-column tiles walked by one workgroup
     size_t plane_stride;  // float2 elements between planes (PH*M)
     size_t img_stride;    // float2 elements between images (grid.z = 3*n_images)
 };

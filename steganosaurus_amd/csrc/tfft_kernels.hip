@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tfft_fft.h"
 #include "tfft_kernels.h"
 
@@ -33,6 +35,10 @@ __device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, 
 // rows, forward: u8 RGB row -> (optional centring) -> zero-pad -> real FFT of
 // length PW -> M half-spectrum bins per plane.   S:383-386, S:392, S:393-398,
 // and the row loop of fft2d S:361.
+// These kernels are instruction-issue bound, not bandwidth bound, so the common
+// case (W % 4 == 0, 4-byte aligned image, 3 planes per workgroup) stages whole
+// 4-pixel groups: one 12-byte load, twelve byte->float conversions and six 8-byte
+// LDS stores per thread instead of per-byte index arithmetic.
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)   T = M/E
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
@@ -46,54 +52,87 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
     LayRows lay{LayRows::padded(M)};
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
+
+    const int nbytes = P.W * 3;
+    const uint8_t* src = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
+    const bool fast = (PPB == 3) && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
 
     // ---- stage the row: bytes -> floats, de-interleaved into the packed (even,odd) layout
-    const size_t rowbase = ((size_t)img * P.H + y) * (size_t)P.W * 3;
-    const uint8_t* src = rgb + rowbase;
-    const int nbytes = P.W * 3;
-    const int head = (int)((4 - ((uintptr_t)src & 3)) & 3);
-    auto put = [&](int off, unsigned byte) {
-        const int n = off / 3, ch = off - 3 * n;
-        const int b = ch - plane0;
-        if (b < 0 || b >= PPB) return;
-        float v = (float)byte;
-        if (P.center && ((n + y) & 1)) v = -v;
-        ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = v;
-    };
-    for (int o = tid; o < head && o < nbytes; o += nthr) put(o, src[o]);
-    const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
-    const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src + head);
-    for (int w = tid; w < nwords; w += nthr) {
-        const uint32_t v = srcw[w];
-        const int o = head + 4 * w;
-        put(o, v & 0xFF); put(o + 1, (v >> 8) & 0xFF); put(o + 2, (v >> 16) & 0xFF); put(o + 3, v >> 24);
-    }
-    for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) put(o, src[o]);
-    for (int n = P.W + tid; n < 2 * M; n += nthr) {   // zero padding W..PW-1
+    if (fast) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;   // (-1)^(x+y), x = 4g+j
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
+        for (int g = tid; g < (P.W >> 2); g += nthr) {
+            const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];   // R0G0B0R1 G1B1R2G2 B2R3G3B3
+            const int i0 = lay.idx(2 * g, 0), i1 = lay.idx(2 * g + 1, 0);
+            lds[i0] = make_float2(s0 * (float)(a & 0xFF), s1 * (float)(a >> 24));
+            lds[i1] = make_float2(s0 * (float)((b >> 16) & 0xFF), s1 * (float)((c >> 8) & 0xFF));
+            lds[i0 + lay.pitch] = make_float2(s0 * (float)((a >> 8) & 0xFF), s1 * (float)(b & 0xFF));
+            lds[i1 + lay.pitch] = make_float2(s0 * (float)(b >> 24), s1 * (float)((c >> 16) & 0xFF));
+            lds[i0 + 2 * lay.pitch] = make_float2(s0 * (float)((a >> 16) & 0xFF), s1 * (float)((b >> 8) & 0xFF));
+            lds[i1 + 2 * lay.pitch] = make_float2(s0 * (float)(c & 0xFF), s1 * (float)(c >> 24));
+        }
+        for (int m = (P.W >> 1) + tid; m < M; m += nthr) {      // zero padding W..PW-1
 #pragma unroll
-        for (int b = 0; b < PPB; b++) ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = 0.0f;
+            for (int b = 0; b < PPB; b++) lds[lay.idx(m, b)] = make_float2(0.f, 0.f);
+        }
+    } else {
+        const int head = (int)((4 - ((uintptr_t)src & 3)) & 3);
+        auto put = [&](int off, unsigned byte) {
+            const int n = off / 3, ch = off - 3 * n;
+            const int b = ch - plane0;
+            if (b < 0 || b >= PPB) return;
+            float v = (float)byte;
+            if (P.center && ((n + y) & 1)) v = -v;
+            ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = v;
+        };
+        for (int o = tid; o < head && o < nbytes; o += nthr) put(o, src[o]);
+        const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src + head);
+        for (int w = tid; w < nwords; w += nthr) {
+            const uint32_t v = srcw[w];
+            const int o = head + 4 * w;
+            put(o, v & 0xFF); put(o + 1, (v >> 8) & 0xFF); put(o + 2, (v >> 16) & 0xFF); put(o + 3, v >> 24);
+        }
+        for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) put(o, src[o]);
+        for (int n = P.W + tid; n < 2 * M; n += nthr) {   // zero padding W..PW-1
+#pragma unroll
+            for (int b = 0; b < PPB; b++) ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = 0.0f;
+        }
     }
+    // twiddles of the radix passes and of the real-FFT split (indices depend on the thread only):
+    // issued before the barrier so their L2 latency overlaps the staging
+    float2 W[tw_regs<M, E>()];
+    fft_prefetch_twiddles<M, E, +1>(W, t, tw, 2);
+    constexpr int NSPLIT = (M / 2) / T + 1;
+    float2 wk[NSPLIT];
+#pragma unroll
+    for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
     __syncthreads();
 
-    // ---- complex FFT of length M on z[m] = x[2m] + i x[2m+1]
+    // ---- complex FFT of length M on z[m] = x[2m] + i x[2m+1].  From here on a thread only touches
+    // its own plane's LDS slab; when that plane is exactly one wave (T == 64) no workgroup barrier is needed.
     float2 u[E];
 #pragma unroll
     for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, pb)];
-    __syncthreads();
-    fft_block<M, E, +1>(u, lds, lay, t, pb, tw, 2);
+    Sync::sync();
+    fft_block<M, E, +1, Sync>(u, lds, lay, t, pb, W);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = u[m];
-    __syncthreads();
+    Sync::sync();
 
     // ---- split into the spectrum of the real row: X[k] = Ev[k] + w^k Od[k], w = exp(+2 pi i/PW)
     float2* dst = out + (size_t)img * P.img_stride + ((size_t)(plane0 + pb) * P.PH + y) * M;
-    for (int k = t; k <= M / 2; k += T) {
+#pragma unroll
+    for (int j = 0; j < NSPLIT; j++) {
+        const int k = t + j * T;
+        if (k > M / 2) break;
         const int k2 = (M - k) & (M - 1);
         const float2 zk = lds[lay.idx(k, pb)], zm = lds[lay.idx(k2, pb)];
         const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // Ev[k]
         const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                        // zk - conj(zm)
         const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);                        // Od[k] = d/(2i)
-        const float2 b = cmul(tw[k], od);
+        const float2 b = cmul(wk[j], od);
         if (k == 0) {
             dst[0] = make_float2(a.x + b.x, a.x - b.x);      // X[0] and X[M], both real, packed
         } else {
@@ -101,6 +140,15 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
             if (k2 != k) dst[k2] = cconj(csub(a, b));
         }
     }
+}
+
+// clamp(round(v), 0, 255) with C round() semantics (half away from zero, S:389) for the values that
+// survive the clamp: negatives go to 0 either way, so only v >= 0 needs exact half-up rounding
+// (v - trunc(v) is exact in fp32, unlike v + 0.5f).
+__device__ __forceinline__ unsigned quantise_u8(float v) {
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    const float r = truncf(v);
+    return (unsigned)r + ((v - r >= 0.5f) ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------
@@ -121,56 +169,81 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
     LayRows lay{LayRows::padded(M)};
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
 
     const float2* src = in + (size_t)img * P.img_stride + ((size_t)(plane0 + pb) * P.PH + y) * M;
-    for (int k = t; k < M; k += T) lds[lay.idx(k, pb)] = src[k];
-    __syncthreads();
+    float2 xin[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) xin[m] = src[t + m * T];
+    float2 W[tw_regs<M, E>()];
+    fft_prefetch_twiddles<M, E, -1>(W, t, tw, 2);
+    float2 wk[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) wk[m] = tw[t + m * T];
+#pragma unroll
+    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = xin[m];
+    Sync::sync();
 
     // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
     float2 u[E];
 #pragma unroll
     for (int m = 0; m < E; m++) {
         const int k = t + m * T;
-        const float2 xk = lds[lay.idx(k, pb)];
+        const float2 xk = xin[m];
         if (k == 0) {
             u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));
         } else {
             const float2 xm = lds[lay.idx(M - k, pb)];
             const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
             const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(tw[k]));
+            const float2 od = cmul(d, cconj(wk[m]));
             u[m] = make_float2(ev.x - od.y, ev.y + od.x);
         }
     }
-    __syncthreads();
-    fft_block<M, E, -1>(u, lds, lay, t, pb, tw, 2);
+    Sync::sync();
+    fft_block<M, E, -1, Sync>(u, lds, lay, t, pb, W);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = cscale(u[m], P.scale);
     __syncthreads();
 
     // ---- quantise and store
-    const size_t rowbase = ((size_t)img * P.H + y) * (size_t)P.W * 3;
-    uint8_t* dst = rgb + rowbase;
     const int nbytes = P.W * 3;
-    auto get = [&](int off) -> unsigned {
-        const int n = off / 3, ch = off - 3 * n;
-        float v = ldsf[2 * lay.idx(n >> 1, ch - plane0) + (n & 1)];
-        if (P.center && ((n + y) & 1)) v = -v;
-        v = fminf(255.0f, fmaxf(0.0f, roundf(v)));     // round(): half away from zero (S:389)
-        return (unsigned)v;
-    };
-    if (PPB == 3) {
-        const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
-        for (int o = tid; o < head && o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
-        const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
-        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + head);
-        for (int w = tid; w < nwords; w += nthr) {
-            const int o = head + 4 * w;
-            dstw[w] = get(o) | (get(o + 1) << 8) | (get(o + 2) << 16) | (get(o + 3) << 24);
+    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
+    const bool fast = (PPB == 3) && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    if (fast) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst);
+        for (int g = tid; g < (P.W >> 2); g += nthr) {
+            const int i0 = lay.idx(2 * g, 0), i1 = lay.idx(2 * g + 1, 0);
+            const float2 r01 = lds[i0], r23 = lds[i1], g01 = lds[i0 + lay.pitch], g23 = lds[i1 + lay.pitch],
+                         b01 = lds[i0 + 2 * lay.pitch], b23 = lds[i1 + 2 * lay.pitch];
+            const unsigned R0 = quantise_u8(s0 * r01.x), R1 = quantise_u8(s1 * r01.y), R2 = quantise_u8(s0 * r23.x), R3 = quantise_u8(s1 * r23.y);
+            const unsigned G0 = quantise_u8(s0 * g01.x), G1 = quantise_u8(s1 * g01.y), G2 = quantise_u8(s0 * g23.x), G3 = quantise_u8(s1 * g23.y);
+            const unsigned B0 = quantise_u8(s0 * b01.x), B1 = quantise_u8(s1 * b01.y), B2 = quantise_u8(s0 * b23.x), B3 = quantise_u8(s1 * b23.y);
+            dstw[3 * g] = R0 | (G0 << 8) | (B0 << 16) | (R1 << 24);
+            dstw[3 * g + 1] = G1 | (B1 << 8) | (R2 << 16) | (G2 << 24);
+            dstw[3 * g + 2] = B2 | (R3 << 8) | (G3 << 16) | (B3 << 24);
         }
-        for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
     } else {
-        for (int n = tid; n < P.W; n += nthr) dst[3 * n + plane0] = (uint8_t)get(3 * n + plane0);
+        auto get = [&](int off) -> unsigned {
+            const int n = off / 3, ch = off - 3 * n;
+            float v = ldsf[2 * lay.idx(n >> 1, ch - plane0) + (n & 1)];
+            if (P.center && ((n + y) & 1)) v = -v;
+            return quantise_u8(v);
+        };
+        if (PPB == 3) {
+            const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
+            for (int o = tid; o < head && o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
+            const int nwords = nbytes > head ? (nbytes - head) / 4 : 0;
+            uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + head);
+            for (int w = tid; w < nwords; w += nthr) {
+                const int o = head + 4 * w;
+                dstw[w] = get(o) | (get(o + 1) << 8) | (get(o + 2) << 16) | (get(o + 3) << 24);
+            }
+            for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
+        } else {
+            for (int n = tid; n < P.W; n += nthr) dst[3 * n + plane0] = (uint8_t)get(3 * n + plane0);
+        }
     }
 }
 
@@ -190,33 +263,56 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
-    const int col = blockIdx.x * C + c;
     const int g = blockIdx.y * blockDim.z + gl;
-    const bool active = (col < P.M) && (g < P.G);
     const int img = blockIdx.z / 3, plane = blockIdx.z - 3 * img;      // grid.z = 3 * n_images
     const size_t plane_off = (size_t)img * P.img_stride + (size_t)plane * P.plane_stride;
-    const float2* src = in + plane_off + col;
-    float2* dst = out + plane_off + col;
     float2* lds = reinterpret_cast<float2*>(tfft_smem) + (size_t)gl * L * C;
     LayColumns lay{C};
 
-    float2 u[E];
+    // A workgroup walks `tiles_per_block` adjacent 16-column tiles.  The twiddles depend on (t, g) only,
+    // so they are fetched once; the next tile's data is fetched into registers while the current tile
+    // is being transformed (the loads of tile i+1 overlap the LDS exchanges and stores of tile i).
+    const int tile0 = blockIdx.x * P.tiles_per_block;
+    const int ntiles = (P.M + C - 1) / C;
+    const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
+    auto load_tile = [&](int tile, float2 (&v)[E]) {
+        const int col = tile * C + c;
+        const bool active = (col < P.M) && (g < P.G);
+        const float2* src = in + plane_off + col;
 #pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int row = P.in_a * (t + m * T) + P.in_b * g;
-        u[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
-    }
-    fft_block<L, E, SIGN>(u, lds, lay, t, c, tw, P.PH >> LOGL);
-    if (!active) return;
-#pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int k = t + m * T;
-        const int row = P.out_a * k + P.out_b * g;
-        if (row < P.out_rows) {
-            float2 v = u[m];
-            if (P.tw_out) v = cmul(v, twload<SIGN>(tw, (k * g) & (P.PH - 1)));
-            dst[(size_t)row * P.M] = v;
+        for (int m = 0; m < E; m++) {
+            const int row = P.in_a * (t + m * T) + P.in_b * g;
+            v[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
         }
+    };
+    float2 u[E], un[E];
+    load_tile(tile0, u);
+    float2 W[tw_regs<L, E>()];
+    fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
+    float2 wo[E];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
+    if (P.tw_out) {
+#pragma unroll
+        for (int m = 0; m < E; m++) wo[m] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
+    }
+    for (int tile = tile0; tile < tile1; tile++) {
+        if (tile + 1 < tile1) load_tile(tile + 1, un);
+        fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
+        const int col = tile * C + c;
+        if ((col < P.M) && (g < P.G)) {
+            float2* dst = out + plane_off + col;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const int k = t + m * T;
+                const int row = P.out_a * k + P.out_b * g;
+                if (row < P.out_rows) {
+                    float2 v = u[m];
+                    if (P.tw_out) v = cmul(v, wo[m]);
+                    dst[(size_t)row * P.M] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) u[m] = un[m];
     }
 }
 
@@ -577,7 +673,8 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
     const size_t lds = (size_t)gpb * L * C * sizeof(float2);
-    dim3 grid((P.M + C - 1) / C, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
+    const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
+    dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

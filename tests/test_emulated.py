@@ -33,6 +33,12 @@ def test_forward_two_step_columns(emu, orc):
     PC.check_forward_against_oracle(emu, orc, [(8, 1024), (20, 600)], centers=(0,))
 
 
+def test_forward_wide_rows_wave_sync_path(emu, orc):
+    # PW = 2048 -> M = 1024 = 64 lanes x 16 elements: the row passes run wave-synchronously (no s_barrier)
+    PC.check_forward_against_oracle(emu, orc, [(1500, 3), (2048, 2)], centers=(0, 1))
+    PC.check_identity_roundtrip(emu, [(1500, 3)])
+
+
 def test_identity_roundtrip(emu):
     PC.check_identity_roundtrip(emu, [(64, 64), (48, 40), (33, 17), (2, 2), (1, 1), (5, 1), (1, 7), (12, 1024)])
 
@@ -91,3 +97,21 @@ def test_batch_matches_single(emu, orc):
         one.forward_rgb8(st)
         assert np.array_equal(one.read_bins(bins), raw[i]), i
     one.close(); ctx.close()
+
+
+def test_unaligned_device_pointers(emu):
+    """Row kernels read/write the u8 rows as aligned 32-bit words: images at odd addresses, odd widths and
+    the first/last word of the whole batch (which straddles the buffer edge) must still be exact."""
+    from steganosaurus_amd.synth import cover_rgb
+    for (w, h, off) in [(7, 5, 1), (33, 6, 3), (40, 9, 2), (5, 3, 0)]:
+        img = cover_rgb(w, h, 2)
+        raw = np.zeros(img.size + 8, np.uint8)
+        raw[off:off + img.size] = img.ravel()
+        outraw = np.zeros(img.size + 8, np.uint8)
+        ctx = B.Context(w, h, lib=emu)
+        ctx.forward_rgb8_dev(raw.ctypes.data + off, w, h)
+        ctx.inverse_rgb8_dev(outraw.ctypes.data + off)
+        ctx.sync()
+        assert np.array_equal(outraw[off:off + img.size].reshape(h, w, 3), img), (w, h, off)
+        assert outraw[:off].sum() == 0 and outraw[off + img.size:].sum() == 0      # nothing written outside
+        ctx.close()
