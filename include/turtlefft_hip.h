@@ -88,6 +88,10 @@ int tfft_forward_rgb8_dev(tfft_ctx* ctx, int slot, const void* rgb_dev, int w, i
  * the FULL padded plane (mirror bins counted).  Synchronises. */
 int tfft_medians(tfft_ctx* ctx, int slot, double med[3]);
 
+/* Diagnostic: how the last tfft_medians / batched median of `slot` was obtained, per plane:
+ * 1 = sampled bracket + one verified pass (fast path), 0 = full three-level select (fallback). */
+int tfft_median_path(tfft_ctx* ctx, int slot, int fast[3]);
+
 /* count_plane (S:998-1008): sum over planes of floor(c/2), c = bins in the
  * annulus [rmin,rmax]*min(PH,PW), off the axes, |F| >= thr[plane].  Synchronises. */
 int tfft_capacity(tfft_ctx* ctx, int slot, double rmin, double rmax, const double thr[3], uint64_t* usable);

@@ -36,6 +36,7 @@ SYMBOLS = {
     "tfft_forward_rgb8": (_i, [_vp, _i, _vp, _i, _i, _i, _pi, _pi]),
     "tfft_forward_rgb8_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _pi, _pi]),
     "tfft_medians": (_i, [_vp, _i, _vp]),
+    "tfft_median_path": (_i, [_vp, _i, _vp]),
     "tfft_capacity": (_i, [_vp, _i, _d, _d, _vp, C.POINTER(_u64)]),
     "tfft_lowfreq_mag": (_i, [_vp, _i, _i, _vp]),
     "tfft_embed_bins": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _d, _i, _vp]),
@@ -201,6 +202,12 @@ class Context:
         med = np.zeros(3, np.float64)
         _check(self.lib.tfft_medians(self.h, slot, _ptr(med)), "tfft_medians")
         return med
+
+    def median_path(self, slot=0):
+        """Per plane: 1 if the last median came from the sampled fast path, 0 if from the full fallback."""
+        out = np.zeros(3, np.int32)
+        _check(self.lib.tfft_median_path(self.h, slot, _ptr(out)), "tfft_median_path")
+        return out
 
     def capacity(self, thr, rmin=0.05, rmax=0.45, slot=0):
         thr = np.ascontiguousarray(thr, np.float64)

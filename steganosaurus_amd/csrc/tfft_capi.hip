@@ -61,6 +61,7 @@ struct tfft_ctx {
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
     int rows_per_block = 8;
+    int median_force_fallback = 0;
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
     float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
@@ -236,7 +237,7 @@ CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax)
 int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st) {
     const Slot& s = c->slots[s0];
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
-                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, st));
+                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, st));
     return TFFT_OK;
 }
 
@@ -304,6 +305,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->device = device; c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots;
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
+    if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_ROWS_PER_BLOCK")) c->rows_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
@@ -394,6 +396,18 @@ int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
     HIPCHK(c, hipMemcpyAsync(m, c->med + 3 * slot, sizeof m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) med[i] = (double)m[i];
+    return TFFT_OK;
+}
+
+int tfft_median_path(tfft_ctx* c, int slot, int fast[3]) {
+    if (!slot_ok(c, slot) || !fast) return TFFT_E_INVALID;
+    SelectState* h = (SelectState*)malloc(3 * sizeof(SelectState));
+    if (!h) return TFFT_E_NOMEM;
+    hipError_t e = hipMemcpyAsync(h, c->sel + 3 * slot, 3 * sizeof(SelectState), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 3; i++) fast[i] = (h[i].done == 1) ? 1 : 0;
+    free(h);
+    if (e != hipSuccess) { c->last_hip = (int)e; return TFFT_E_HIP; }
     return TFFT_OK;
 }
 
@@ -570,7 +584,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     const ColPlan pl = plan_cols(c, s.PH);
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
-    if (stage == MEDIANS) launches = 7;
+    if (stage == MEDIANS) launches = c->median_force_fallback ? 7 : 13;
     if (stage == CAPACITY) launches = 2;
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;

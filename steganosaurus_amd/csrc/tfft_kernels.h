@@ -57,8 +57,12 @@ struct CapParams {
 struct SelectState {        // one per (image, plane)
     unsigned hist[4096];
     unsigned long long rank;
+    unsigned long long below;   // fast path: exact weight of everything below the bracket
     unsigned prefix;
     unsigned n_cand;
+    unsigned lo, hi;            // fast path: bracket of level-1 buckets around the sample median
+    unsigned done;              // 0 open / fallback needed, 2 fast path verified at level 2, 1 median written
+    unsigned pad;
 };
 
 hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
@@ -72,7 +76,7 @@ hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits,
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
                        int n_images, uint8_t* bits_out, int* err, hipStream_t s);
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
-                          unsigned* cand, size_t cand_stride, float* med_out, hipStream_t s);
+                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, hipStream_t s);
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s);
 hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);

@@ -413,14 +413,21 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
 
 // ---------------------------------------------------------------------------
 // median_abs S:404-409: the exact order statistic (sorted index P/2) of |F| over
-// the full plane, as a 3-level radix select on the float bit pattern:
-//   level 1: 4096-bucket histogram (sign+exponent+4 mantissa bits) of the spectrum
-//   collect: the members of the selected bucket are compacted (low 19 bits + weight)
-//   level 2/3: 1024- and 512-bucket histograms of the compacted candidates
-// Stored bins of columns 1..M-1 count twice (bin + Hermitian mirror); the packed
-// column 0 yields F[.][0] and F[.][M] once each.
-// Grids are a few blocks per CU with row loops: thousands of blocks adding to the
-// same few global counters serialise at ~11 ns per atomic.
+// the full plane.  Stored bins of columns 1..M-1 count twice (bin + Hermitian
+// mirror); the packed column 0 yields F[.][0] and F[.][M] once each.
+//
+// FAST path (one full read of the spectrum):
+//   1. k_hist_spec over every 16th row: 4096-bucket histogram (top 13 bits of the float) of a SAMPLE
+//   2. k_select_guess: bucket b of the sample median -> bracket [b-1, b+1]
+//   3. k_collect_bracket over everything: exact weight below the bracket + compaction of the members
+//      of the bracket (value relative to the bracket start, 21 bits) + their 1024-bucket histogram
+//   4. k_select_fast<2>: rank - weight_below must fall inside the bracket (this VERIFIES the guess:
+//      the result is exact or the path declares failure), pick the level-2 bucket
+//   5. k_hist_cand / k_select_fast<3>: 2048-bucket level over the candidates -> the exact median
+// FALLBACK (only if step 4 fails; every kernel returns at once when st->done): the plain 3-level radix
+// select (4096 / 1024 / 512 buckets) with a full histogram pass and a compaction pass.
+// Grids are a few blocks per CU with row loops and LDS-staged results: thousands of blocks adding to
+// the same few global counters serialise at ~11 ns per atomic.
 //   grid (NB, 3, n_images)   block 256   st[img*3+plane]
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ SelectState* sel_of(SelectState* st) { return st + (size_t)blockIdx.z * 3 + blockIdx.y; }
@@ -435,69 +442,221 @@ __device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int 
     }
 }
 
+// histogram of rows y0, y0+row_step, ... ; guarded != 0: fallback role, skip when the fast path succeeded
 __global__ void k_hist_spec(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
-                            SelectState* __restrict__ st) {
+                            SelectState* __restrict__ st, int row_step, int guarded) {
+    SelectState* s = sel_of(st);
+    if (guarded && s->done) return;
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 4096 counters
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
-    for (int y = blockIdx.x; y < PH; y += gridDim.x)
+    for (int y = blockIdx.x * row_step; y < PH; y += gridDim.x * row_step)
         for (int x = threadIdx.x; x < M; x += blockDim.x)
             for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); });
     __syncthreads();
-    SelectState* s = sel_of(st);
     for (int i = threadIdx.x; i < 4096; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
 }
 
-// One block of 256 threads per (image, plane): find the bucket that holds rank s->rank among
-// NB buckets (three-level sum so that no thread walks more than 16 LDS words), clear the
-// histogram for the next level, update prefix/rank.
-template <int LEVEL>
-__global__ void k_select(SelectState* __restrict__ st, float* __restrict__ med_out) {
-    constexpr int NB = (LEVEL == 1) ? 4096 : (LEVEL == 2) ? 1024 : 512;
-    constexpr int SHIFT = (LEVEL == 1) ? 0 : (LEVEL == 2) ? 10 : 9;
-    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem);          // NB + 256 + 16 words
-    unsigned* p1 = h + 4096;
-    unsigned* p2 = p1 + 256;
-    SelectState* s = st + blockIdx.x;
+// Bucket holding `rank` among NB <= 4096 counters staged in LDS (h[4096] zero padded, p1[256], p2[16]):
+// three-level sums so that no thread walks more than 16 LDS words.  All 256 threads call; the result
+// (bucket, weight before it) is valid in thread 0.
+__device__ __forceinline__ void find_bucket(unsigned* h, unsigned* p1, unsigned* p2, unsigned long long rank, int nb,
+                                            int& bucket, unsigned long long& before) {
     const int t = threadIdx.x;
-    for (int i = t; i < 4096; i += 256) { h[i] = (i < NB) ? s->hist[i] : 0u; }
-    __syncthreads();
     { unsigned a = 0; for (int i = 0; i < 16; i++) a += h[t * 16 + i]; p1[t] = a; }
     __syncthreads();
     if (t < 16) { unsigned a = 0; for (int i = 0; i < 16; i++) a += p1[t * 16 + i]; p2[t] = a; }
     __syncthreads();
+    bucket = nb - 1; before = 0;
     if (t == 0) {
-        unsigned long long rank = s->rank, cum = 0;
+        unsigned long long cum = 0;
         int g2 = 15; for (int i = 0; i < 16; i++) { if (cum + p2[i] > rank) { g2 = i; break; } cum += p2[i]; }
         int g1 = g2 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + p1[g2 * 16 + i] > rank) { g1 = g2 * 16 + i; break; } cum += p1[g2 * 16 + i]; }
         int b = g1 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + h[g1 * 16 + i] > rank) { b = g1 * 16 + i; break; } cum += h[g1 * 16 + i]; }
-        if (b >= NB) b = NB - 1;
-        s->rank = rank - cum;
-        s->prefix = (LEVEL == 1) ? (unsigned)b : ((s->prefix << SHIFT) | (unsigned)b);
-        if (LEVEL == 3) med_out[blockIdx.x] = __uint_as_float(s->prefix);
+        if (b >= nb) b = nb - 1;
+        bucket = b; before = cum;
     }
+}
+__device__ __forceinline__ unsigned long long stage_hist(const SelectState* s, unsigned* h, int nb) {
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = (i < nb) ? s->hist[i] : 0u;
     __syncthreads();
-    for (int i = t; i < 4096; i += 256) s->hist[i] = 0;
+    return 0;
 }
 
 __global__ void k_select_init(SelectState* __restrict__ st, unsigned long long rank) {
     SelectState* s = st + blockIdx.x;
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) s->hist[i] = 0;
-    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; }
+    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->lo = 0; s->hi = 0; }
 }
 
-// Compaction of the selected level-1 bucket: candidates are staged in LDS (<= 2 per element of
-// a 1024-element chunk), one global atomic per chunk reserves the output range.  Each candidate
-// is (low 19 bits of the magnitude) | (weight 2 ? 1<<31 : 0).  Also accumulates the level-2
-// histogram of what it appends.
+// ---- fast path ----------------------------------------------------------------------------------
+__global__ void k_select_guess(SelectState* __restrict__ st) {
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
+    SelectState* s = st + blockIdx.x;
+    stage_hist(s, h, 4096);
+    // total sample weight = sum of the histogram; its median rank = total/2
+    unsigned long long& total = *reinterpret_cast<unsigned long long*>(p2 + 16);
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    { unsigned long long a = 0; for (int i = threadIdx.x; i < 4096; i += 256) a += h[i]; atomicAdd(&total, a); }
+    __syncthreads();
+    int b; unsigned long long before;
+    find_bucket(h, p1, p2, total / 2, 4096, b, before);
+    if (threadIdx.x == 0) { s->lo = (unsigned)(b > 0 ? b - 1 : 0); s->hi = (unsigned)(b < 4095 ? b + 1 : 4095); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
+}
+
+// One pass over the whole spectrum: weight of everything below the bracket (registers -> one atomic per
+// block) and compaction of the bracket's members.  Each WAVE stages its candidates in a private LDS
+// buffer and flushes it with one global atomic when it is half full: no workgroup barrier in the loop.
+__global__ void k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
+                                  SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
+    unsigned* wbuf = hist + 1024;                                 // 4 waves x 256 staged candidates
+    unsigned* wcnt = wbuf + 4 * 256;                              // per wave: [0] staged count, [1] global base
+    SelectState* s = sel_of(st);
+    const unsigned lo = s->lo, hi = s->hi, base_bits = lo << 19;
+    unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned* buf = wbuf + wave * 256; unsigned* cnt = wcnt + wave * 2;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+    if (lane == 0) cnt[0] = 0;
+    __syncthreads();
+    unsigned long long below = 0;
+    // every wave walks whole rows in steps of 64 columns; the trip counts are wave uniform
+    for (int y = blockIdx.x * 4 + wave; y < PH; y += gridDim.x * 4) {
+        for (int x0 = 0; x0 < M; x0 += 64) {
+            const int x = x0 + lane;
+            if (x < M)
+                for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
+                    const unsigned bk = b >> 19;
+                    if (bk < lo) below += w;
+                    else if (bk <= hi) {
+                        const unsigned rel = b - base_bits;                      // < 3 * 2^19
+                        buf[atomicAdd(&cnt[0], 1u)] = rel | (w == 2u ? 0x80000000u : 0u);
+                        atomicAdd(&hist[rel >> 11], w);
+                    }
+                });
+            WaveSync::sync();
+            const unsigned n = cnt[0];
+            if (n > 128) {                                                       // at most 128 more fit per step
+                if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, n);
+                WaveSync::sync();
+                const unsigned gbase = cnt[1];
+                for (unsigned i = lane; i < n; i += 64) out[gbase + i] = buf[i];
+                WaveSync::sync();
+                if (lane == 0) cnt[0] = 0;
+            }
+            WaveSync::sync();
+        }
+    }
+    {   // final flush of this wave
+        const unsigned n = cnt[0];
+        if (n) {
+            if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, n);
+            WaveSync::sync();
+            const unsigned gbase = cnt[1];
+            for (unsigned i = lane; i < n; i += 64) out[gbase + i] = buf[i];
+        }
+    }
+    if (below) atomicAdd(&s->below, below);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// LEVEL 2: verify the bracket and pick the 2048-wide sub-bucket; LEVEL 3: the exact value.
+template <int LEVEL>
+__global__ void k_select_fast(SelectState* __restrict__ st, float* __restrict__ med_out) {
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
+    SelectState* s = st + blockIdx.x;
+    if (LEVEL == 3 && s->done != 2) return;            // level 2 did not verify: leave everything to the fallback
+    constexpr int NB = (LEVEL == 2) ? 1024 : 2048;
+    stage_hist(s, h, NB);
+    unsigned long long& total = *reinterpret_cast<unsigned long long*>(p2 + 16);
+    int& ok = *reinterpret_cast<int*>(p2 + 18);
+    if (threadIdx.x == 0) { total = 0; ok = 1; }
+    __syncthreads();
+    { unsigned long long a = 0; for (int i = threadIdx.x; i < 4096; i += 256) a += h[i]; atomicAdd(&total, a); }
+    __syncthreads();
+    unsigned long long rank = s->rank;
+    if (LEVEL == 2) {
+#ifdef TFFT_DEBUG_MEDIAN
+        if (threadIdx.x == 0) printf("sel2 plane %d: rank %llu below %llu total %llu lo %u hi %u n_cand %u\n", (int)blockIdx.x, rank, s->below, total, s->lo, s->hi, s->n_cand);
+#endif
+        if (threadIdx.x == 0 && (rank < s->below || rank - s->below >= total)) ok = 0;
+        rank -= s->below;
+    }
+    __syncthreads();
+    if (ok) {
+        int b; unsigned long long before;
+        find_bucket(h, p1, p2, rank, NB, b, before);
+        if (threadIdx.x == 0) {
+            if (LEVEL == 2) { s->prefix = (unsigned)b; s->rank = rank - before; s->done = 2; }
+            else { med_out[blockIdx.x] = __uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b); s->done = 1; }
+        }
+    } else if (threadIdx.x == 0) {
+        s->n_cand = 0; s->prefix = 0; s->done = 0;      // s->rank is untouched: the fallback starts from it
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
+}
+
+// histogram of one level over the compacted candidates.  FAST: 2048 buckets of (rel & 2047) among the
+// candidates whose rel>>11 equals the level-2 bucket; fallback: 512 buckets of (c & 511) among c>>9 == want.
+template <bool FAST>
+__global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
+    SelectState* s = sel_of(st);
+    if (FAST ? (s->done != 2) : (s->done != 0)) return;
+    constexpr int NB = FAST ? 2048 : 512;
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const unsigned want = FAST ? s->prefix : (s->prefix & 1023u), n = s->n_cand;
+    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned c = in[i], v = c & 0x7FFFFFFFu;
+        if (FAST) { if ((v >> 11) == want) atomicAdd(&hist[v & 2047u], (c >> 31) ? 2u : 1u); }
+        else { if (((v >> 9) & 1023u) == want) atomicAdd(&hist[v & 511u], (c >> 31) ? 2u : 1u); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// ---- fallback path (plain 3-level radix select; every kernel is a no-op when s->done) ---------------
+template <int LEVEL>
+__global__ void k_select(SelectState* __restrict__ st, float* __restrict__ med_out) {
+    constexpr int NB = (LEVEL == 1) ? 4096 : (LEVEL == 2) ? 1024 : 512;
+    constexpr int SHIFT = (LEVEL == 1) ? 0 : (LEVEL == 2) ? 10 : 9;
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
+    SelectState* s = st + blockIdx.x;
+    if (s->done) return;
+    stage_hist(s, h, NB);
+    int b; unsigned long long before;
+    const unsigned long long rank = s->rank;
+    find_bucket(h, p1, p2, rank, NB, b, before);
+    if (threadIdx.x == 0) {
+        s->rank = rank - before;
+        s->prefix = (LEVEL == 1) ? (unsigned)b : ((s->prefix << SHIFT) | (unsigned)b);
+        if (LEVEL == 3) med_out[blockIdx.x] = __uint_as_float(s->prefix);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
+}
+
+// Compaction of the selected level-1 bucket (candidate = low 19 bits | weight flag) + its level-2 histogram.
 __global__ void k_collect(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
                           SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+    SelectState* s = sel_of(st);
+    if (s->done) return;
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
     unsigned* buf = hist + 1024;                                  // 2048 staged candidates
     unsigned* cnt = buf + 2048;                                   // [0] staged count, [1] global base
-    SelectState* s = sel_of(st);
     const unsigned prefix = s->prefix;
     unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
     const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
@@ -527,23 +686,6 @@ __global__ void k_collect(const float2* __restrict__ spec, int PH, int M, size_t
         }
     }
     for (int i = threadIdx.x; i < 1024; i += blockDim.x)
-        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
-}
-
-// level-3 histogram over the compacted candidates (those in the level-2 bucket)
-__global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
-    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 512 counters
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    SelectState* s = sel_of(st);
-    const unsigned want = s->prefix & 1023u, n = s->n_cand;
-    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned c = in[i];
-        if (((c >> 9) & 1023u) == want) atomicAdd(&hist[c & 511u], (c >> 31) ? 2u : 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
 }
 
@@ -719,19 +861,33 @@ static unsigned stat_blocks(int rows, int n_images) {
 }
 
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
-                          unsigned* cand, size_t cand_stride, float* med_out, hipStream_t s) {
+                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, hipStream_t s) {
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
     const unsigned nb = stat_blocks(PH, n_images);
-    const unsigned sel_lds = (4096 + 256 + 16) * sizeof(unsigned);
-    hipLaunchKernelGGL(k_select_init, dim3(3 * n_images), dim3(256), 0, s, st, rank);
-    hipLaunchKernelGGL(k_hist_spec, dim3(nb, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st);
-    hipLaunchKernelGGL(k_select<1>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
-    hipLaunchKernelGGL(k_collect, dim3(nb, 3, n_images), dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M,
-                       img_stride, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select<2>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
-    hipLaunchKernelGGL(k_hist_cand, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select<3>, dim3(3 * n_images), dim3(256), sel_lds, s, st, med_out);
+    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    const dim3 g3(nb, 3, n_images), gs(3 * n_images);
+    hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
+    if (!force_fallback) {
+        // fast path: sample histogram -> bracket -> one verified pass
+        int step = PH / 128; if (step < 1) step = 1; if (step > 16) step = 16;      // sample every step-th row
+        unsigned nbs = (unsigned)((PH + step - 1) / step); if (nbs > nb) nbs = nb; if (nbs < 1) nbs = 1;
+        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
+        hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st);
+        unsigned nbc = (unsigned)((PH + 3) / 4); if (nbc > nb) nbc = nb; if (nbc < 1) nbc = 1;
+        hipLaunchKernelGGL(k_collect_bracket, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 256 + 8) * sizeof(unsigned), s, spec, PH, M,
+                           img_stride, st, cand, cand_stride);
+        hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
+        hipLaunchKernelGGL(k_hist_cand<true>, dim3(16, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
+        hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    }
+    // fallback: plain three-level select; every block returns immediately when the fast path verified
+    hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1);
+    hipLaunchKernelGGL(k_select<1>, gs, dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_collect, g3, dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M, img_stride, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_hist_cand<false>, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select<3>, gs, dim3(256), sel_lds, s, st, med_out);
     return hipGetLastError();
 }
 

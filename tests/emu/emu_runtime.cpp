@@ -12,7 +12,7 @@ namespace tfft { alignas(16) unsigned char tfft_smem[160 * 1024]; }
 
 namespace {
 constexpr size_t STACK = 256 * 1024;
-struct Fiber { ucontext_t ctx; emu_idx tid; bool done; };
+struct Fiber { ucontext_t ctx; emu_idx tid; bool done; int waiting; };   // waiting: 0 running, 1 at a block barrier, 2 at a wave barrier
 ucontext_t sched_ctx;
 std::vector<Fiber> fibers;
 std::vector<char*> stacks;
@@ -26,7 +26,8 @@ void trampoline() {
 }
 }  // namespace
 
-void emu_syncthreads() { swapcontext(&current->ctx, &sched_ctx); }
+void emu_syncthreads() { current->waiting = 1; swapcontext(&current->ctx, &sched_ctx); }
+void emu_wave_sync() { current->waiting = 2; swapcontext(&current->ctx, &sched_ctx); }
 
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     if (shmem > sizeof(tfft::tfft_smem)) { fprintf(stderr, "emu: %zu bytes of LDS requested\n", shmem); abort(); }
@@ -46,20 +47,33 @@ void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>
                     for (unsigned ty = 0; ty < block.y; ty++)
                         for (unsigned tx = 0; tx < block.x; tx++, i++) {
                             Fiber& f = fibers[i];
-                            f.tid = {tx, ty, tz}; f.done = false;
+                            f.tid = {tx, ty, tz}; f.done = false; f.waiting = 0;
                             getcontext(&f.ctx);
                             f.ctx.uc_stack.ss_sp = stacks[i]; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
                             makecontext(&f.ctx, trampoline, 0);
                         }
+                // Scheduler with real barrier semantics: a fiber parked at a block barrier resumes only when
+                // every live fiber of the block is parked there; one parked at a wave barrier resumes when every
+                // live fiber of its wave (64 consecutive linear thread ids) is parked at a wave barrier.
                 size_t live = nt;
-                while (live) {           // one round = every live fiber runs up to its next barrier
-                    for (size_t k = 0; k < nt; k++) {
-                        Fiber& f = fibers[k];
-                        if (f.done) continue;
-                        current = &f; threadIdx = f.tid;
-                        swapcontext(&sched_ctx, &f.ctx);
-                        if (f.done) live--;
+                auto run = [&](Fiber& f) {
+                    f.waiting = 0; current = &f; threadIdx = f.tid;
+                    swapcontext(&sched_ctx, &f.ctx);
+                    if (f.done) live--;
+                };
+                while (live) {
+                    bool progressed = false;
+                    for (size_t k = 0; k < nt; k++) if (!fibers[k].done && fibers[k].waiting == 0) { run(fibers[k]); progressed = true; }
+                    for (size_t w0 = 0; w0 < nt; w0 += 64) {          // wave barriers
+                        const size_t w1 = w0 + 64 < nt ? w0 + 64 : nt;
+                        bool any = false, all = true;
+                        for (size_t k = w0; k < w1; k++) if (!fibers[k].done) { any = true; if (fibers[k].waiting != 2) all = false; }
+                        if (any && all) { for (size_t k = w0; k < w1; k++) if (!fibers[k].done) run(fibers[k]); progressed = true; }
                     }
+                    bool any = false, all = true;                      // block barrier
+                    for (size_t k = 0; k < nt; k++) if (!fibers[k].done) { any = true; if (fibers[k].waiting != 1) all = false; }
+                    if (any && all) { for (size_t k = 0; k < nt; k++) if (!fibers[k].done) run(fibers[k]); progressed = true; }
+                    if (!progressed && live) { fprintf(stderr, "emu: barrier deadlock (divergent barriers) in block %u,%u,%u\n", bx, by, bz); abort(); }
                 }
             }
     body_fn = nullptr;

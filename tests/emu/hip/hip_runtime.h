@@ -45,9 +45,10 @@ struct hipDeviceProp_t { char gcnArchName[64]; };
 
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void emu_syncthreads();
+void emu_wave_sync();
 #define __syncthreads() emu_syncthreads()
-// wave-level sync points of the kernels: in the fiber model every sync is a yield
-#define __builtin_amdgcn_wave_barrier() emu_syncthreads()
+// wave-level sync points of the kernels: a barrier among the 64 fibers of the wave
+#define __builtin_amdgcn_wave_barrier() emu_wave_sync()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu_launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

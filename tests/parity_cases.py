@@ -100,6 +100,37 @@ def check_forward_golden(lib, golden_dir, wh, center):
     ctx.close()
 
 
+def check_median_paths(lib, orc, sizes):
+    """The sampled fast path and the forced full fallback give the same exact order statistic; on
+    ordinary covers the fast path is the one that runs."""
+    for (w, h) in sizes:
+        img = cover_rgb(w, h, 4)
+        _, want = orc.forward_rgb8(img, want_spec=False)
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["TFFT_MEDIAN_FALLBACK"] = mode
+            try:
+                ctx = B.Context(w, h, lib=lib)
+            finally:
+                os.environ.pop("TFFT_MEDIAN_FALLBACK", None)
+            ctx.forward_rgb8(img)
+            res[mode] = (ctx.medians().copy(), ctx.median_path().copy())
+            ctx.close()
+        assert np.array_equal(res["0"][0], res["1"][0]), (w, h, res)
+        assert np.allclose(res["0"][0], want, rtol=2e-6)
+        assert res["1"][1].sum() == 0
+        if w * h >= 64 * 64:
+            assert res["0"][1].sum() == 3, ("fast path not taken", w, h, res["0"][1])
+    # degenerate spectrum (constant image: every AC magnitude ~0): whatever path runs, the answer is exact
+    flat = np.full((32, 32, 3), 77, np.uint8)
+    ctx = B.Context(32, 32, lib=lib)
+    ctx.forward_rgb8(flat)
+    m = ctx.medians()
+    _, want = orc.forward_rgb8(flat, want_spec=False)
+    assert np.all(np.abs(m - want) <= 1e-3), (m, want)
+    ctx.close()
+
+
 def check_identity_roundtrip(lib, sizes):
     """forward -> inverse with no embedding returns the cover exactly (integers survive fp32)."""
     for (w, h) in sizes:

@@ -39,6 +39,10 @@ def test_forward_wide_rows_wave_sync_path(emu, orc):
     PC.check_identity_roundtrip(emu, [(1500, 3)])
 
 
+def test_median_fast_and_fallback_paths(emu, orc):
+    PC.check_median_paths(emu, orc, [(64, 64), (48, 40), (8, 4), (128, 32)])
+
+
 def test_identity_roundtrip(emu):
     PC.check_identity_roundtrip(emu, [(64, 64), (48, 40), (33, 17), (2, 2), (1, 1), (5, 1), (1, 7), (12, 1024)])
 

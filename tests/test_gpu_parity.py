@@ -79,6 +79,10 @@ def test_forward_512_golden_sample(lib, golden_dir, name):
     ctx.close()
 
 
+def test_median_fast_and_fallback_paths(lib, orc):
+    PC.check_median_paths(lib, orc, [(64, 64), (48, 40), (8, 4), (512, 512), (1920, 1080)])
+
+
 def test_identity_roundtrip(lib):
     PC.check_identity_roundtrip(lib, [(64, 64), (48, 40), (33, 17), (2, 2), (1, 1), (5, 1), (1, 7), (12, 1024),
                                       (512, 512), (1920, 1080), (3840, 2160)])
