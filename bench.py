@@ -199,9 +199,22 @@ def main():
         ctx.sync()
         two_step = PH > 512 and not os.environ.get("TFFT_COLS_DIRECT_MAX_LOG")
         stages = {}
-        for sid, name in enumerate(S.Context.STAGES):
-            ms, nl = ctx.profile_stage(sid, args.stage_reps, d_img.data_ptr(), d_stego.data_ptr(), d_bins.data_ptr(),
-                                       d_bits.data_ptr(), d_raw.data_ptr(), n_bits, n_images=slots)
+
+        def prof(sid, reps):
+            return ctx.profile_stage(sid, reps, d_img.data_ptr(), d_stego.data_ptr(), d_bins.data_ptr(),
+                                     d_bits.data_ptr(), d_raw.data_ptr(), n_bits, n_images=slots)
+
+        # the two-step column stages work in place, so repeating one of them destroys its input: time the
+        # forward stages first, rebuild a clean spectrum, then time everything that reads the spectrum, and
+        # the inverse stages last
+        order = [0, 1, 2, "clean", 8, 9, 3, 7, 4, 5, 6]
+        for sid in order:
+            if sid == "clean":
+                for k in (0, 1, 2):
+                    prof(k, 1)
+                continue
+            name = S.Context.STAGES[sid]
+            ms, nl = prof(sid, args.stage_reps)
             if nl == 0:
                 continue
             kb = kernel_bytes(name, W, H, n_bits, two_step) * slots

@@ -432,13 +432,17 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ SelectState* sel_of(SelectState* st) { return st + (size_t)blockIdx.z * 3 + blockIdx.y; }
 
+// The selection works on |F|^2 (the argument of mag_of's square root): sqrtf is monotone, so the element at
+// a given rank is the same and the median is the square root of the selected value -- one sqrt per plane
+// instead of one per bin.
+__device__ __forceinline__ float mag2_of(float2 v) { return fmaf(v.x, v.x, v.y * v.y); }
 template <class F>
 __device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f) {
     if (x == 0) {
         float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
-        f(__float_as_uint(mag_of(f0)), 1u); f(__float_as_uint(mag_of(fm)), 1u);
+        f(__float_as_uint(mag2_of(f0)), 1u); f(__float_as_uint(mag2_of(fm)), 1u);
     } else {
-        f(__float_as_uint(mag_of(pl[(size_t)y * M + x])), 2u);
+        f(__float_as_uint(mag2_of(pl[(size_t)y * M + x])), 2u);
     }
 }
 
@@ -515,35 +519,38 @@ __global__ void k_select_guess(SelectState* __restrict__ st) {
 __global__ void k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
                                   SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
-    unsigned* wbuf = hist + 1024;                                 // 4 waves x 256 staged candidates
-    unsigned* wcnt = wbuf + 4 * 256;                              // per wave: [0] staged count, [1] global base
+    unsigned* wbuf = hist + 1024;                                 // 4 waves x 512 staged candidates
+    unsigned* wcnt = wbuf + 4 * 512;                              // per wave: [0] staged count, [1] global base
     SelectState* s = sel_of(st);
     const unsigned lo = s->lo, hi = s->hi, base_bits = lo << 19;
     unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
     const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned* buf = wbuf + wave * 256; unsigned* cnt = wcnt + wave * 2;
+    unsigned* buf = wbuf + wave * 512; unsigned* cnt = wcnt + wave * 2;
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
     if (lane == 0) cnt[0] = 0;
     __syncthreads();
     unsigned long long below = 0;
-    // every wave walks whole rows in steps of 64 columns; the trip counts are wave uniform
+    // every wave walks whole rows in steps of 256 columns (4 per lane); the trip counts are wave uniform
     for (int y = blockIdx.x * 4 + wave; y < PH; y += gridDim.x * 4) {
-        for (int x0 = 0; x0 < M; x0 += 64) {
-            const int x = x0 + lane;
-            if (x < M)
-                for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
-                    const unsigned bk = b >> 19;
-                    if (bk < lo) below += w;
-                    else if (bk <= hi) {
-                        const unsigned rel = b - base_bits;                      // < 3 * 2^19
-                        buf[atomicAdd(&cnt[0], 1u)] = rel | (w == 2u ? 0x80000000u : 0u);
-                        atomicAdd(&hist[rel >> 11], w);
-                    }
-                });
+        for (int x0 = 0; x0 < M; x0 += 256) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int x = x0 + q * 64 + lane;
+                if (x < M)
+                    for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
+                        const unsigned bk = b >> 19;
+                        if (bk < lo) below += w;
+                        else if (bk <= hi) {
+                            const unsigned rel = b - base_bits;                  // < 3 * 2^19
+                            buf[atomicAdd(&cnt[0], 1u)] = rel | (w == 2u ? 0x80000000u : 0u);
+                            atomicAdd(&hist[rel >> 11], w);
+                        }
+                    });
+            }
             WaveSync::sync();
             const unsigned n = cnt[0];
-            if (n > 128) {                                                       // at most 128 more fit per step
+            if (n > 250) {                                                       // at most 4*65 more fit per step
                 if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, n);
                 WaveSync::sync();
                 const unsigned gbase = cnt[1];
@@ -597,7 +604,7 @@ __global__ void k_select_fast(SelectState* __restrict__ st, float* __restrict__ 
         find_bucket(h, p1, p2, rank, NB, b, before);
         if (threadIdx.x == 0) {
             if (LEVEL == 2) { s->prefix = (unsigned)b; s->rank = rank - before; s->done = 2; }
-            else { med_out[blockIdx.x] = __uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b); s->done = 1; }
+            else { med_out[blockIdx.x] = sqrtf(__uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b)); s->done = 1; }
         }
     } else if (threadIdx.x == 0) {
         s->n_cand = 0; s->prefix = 0; s->done = 0;      // s->rank is untouched: the fallback starts from it
@@ -643,7 +650,7 @@ __global__ void k_select(SelectState* __restrict__ st, float* __restrict__ med_o
     if (threadIdx.x == 0) {
         s->rank = rank - before;
         s->prefix = (LEVEL == 1) ? (unsigned)b : ((s->prefix << SHIFT) | (unsigned)b);
-        if (LEVEL == 3) med_out[blockIdx.x] = __uint_as_float(s->prefix);
+        if (LEVEL == 3) med_out[blockIdx.x] = sqrtf(__uint_as_float(s->prefix));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
@@ -875,7 +882,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
         hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st);
         unsigned nbc = (unsigned)((PH + 3) / 4); if (nbc > nb) nbc = nb; if (nbc < 1) nbc = 1;
-        hipLaunchKernelGGL(k_collect_bracket, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 256 + 8) * sizeof(unsigned), s, spec, PH, M,
+        hipLaunchKernelGGL(k_collect_bracket, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                            img_stride, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
         hipLaunchKernelGGL(k_hist_cand<true>, dim3(16, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
