@@ -56,10 +56,26 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
 
     const int nbytes = P.W * 3;
     const uint8_t* src = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
-    const bool fast = (PPB == 3) && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    const bool aligned4 = ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    const bool fast = (PPB == 3) && aligned4;
 
     // ---- stage the row: bytes -> floats, de-interleaved into the packed (even,odd) layout
-    if (fast) {
+    if (PPB == 1 && aligned4) {
+        // one plane per workgroup: the same 12-byte groups, keeping the four samples of this plane
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
+        const int sh = 8 * plane0;      // byte lane of this plane inside a pixel
+        for (int g = tid; g < (P.W >> 2); g += nthr) {
+            const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];
+            const uint64_t lo = ((uint64_t)b << 32) | a;                 // bytes 0..7
+            const uint64_t hi = ((uint64_t)c << 32) | b;                 // bytes 4..11
+            const float v0 = (float)((lo >> sh) & 0xFF), v1 = (float)((lo >> (sh + 24)) & 0xFF);
+            const float v2 = (float)((hi >> (sh + 16)) & 0xFF), v3 = (float)((hi >> (sh + 40)) & 0xFF);
+            lds[lay.idx(2 * g, 0)] = make_float2(s0 * v0, s1 * v1);
+            lds[lay.idx(2 * g + 1, 0)] = make_float2(s0 * v2, s1 * v3);
+        }
+        for (int m = (P.W >> 1) + tid; m < M; m += nthr) lds[lay.idx(m, 0)] = make_float2(0.f, 0.f);
+    } else if (fast) {
         const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;   // (-1)^(x+y), x = 4g+j
         const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
         for (int g = tid; g < (P.W >> 2); g += nthr) {
@@ -771,7 +787,7 @@ __global__ void k_lowfreq(const float2* __restrict__ spec, int PH, int PW, int r
         default: return hipErrorInvalidValue;                                                     \
     }
 
-constexpr int rows_ppb(int logm) { return logm <= 11 ? 3 : 1; }   // 3 planes/block while 3*M*8 B fits LDS comfortably
+constexpr int rows_ppb(int logm) { return logm <= 10 ? 3 : 1; }   // wide rows: one plane (few waves) per workgroup   // 3 planes/block while 3*M*8 B fits LDS comfortably
 
 template <int LOGM, int PPB, bool FWD>
 static hipError_t launch_rows_t(const void* in, void* out, const float2* tw, const RowParams& P, int n_images,

@@ -37,6 +37,9 @@ def test_forward_wide_rows_wave_sync_path(emu, orc):
     # PW = 2048 -> M = 1024 = 64 lanes x 16 elements: the row passes run wave-synchronously (no s_barrier)
     PC.check_forward_against_oracle(emu, orc, [(1500, 3), (2048, 2)], centers=(0, 1))
     PC.check_identity_roundtrip(emu, [(1500, 3)])
+    # PW = 4096 -> M = 2048: one plane per workgroup (two waves), own fast staging path; 2101 is not a multiple of 4
+    PC.check_forward_against_oracle(emu, orc, [(2100, 2), (2101, 2)], centers=(0, 1))
+    PC.check_identity_roundtrip(emu, [(2100, 3), (2101, 2)])
 
 
 def test_median_fast_and_fallback_paths(emu, orc):
