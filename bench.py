@@ -56,6 +56,12 @@ def model_bytes(w, h, n_bits):
     return b_embed, b_extract
 
 
+def fused_plan(w, h):
+    """k_rowcol_fwd / k_colrow_inv (rows fused with the adjacent length-8 column step) are used for
+    images that pad to 2048 columns and at least 128 rows (tfft_capi.hip plan_cols)."""
+    return max(2, next_pow2(w)) == 2048 and next_pow2(h) >= 128 and os.environ.get("TFFT_FUSE", "1") != "0"
+
+
 def kernel_bytes(stage, w, h, n_bits, two_step):
     """Compulsory HBM bytes of each kernel in THIS implementation's layout (half spectrum,
     rows >= H skipped where the data is known to be zero / not needed).  DESIGN.md section 4."""
@@ -64,6 +70,14 @@ def kernel_bytes(stage, w, h, n_bits, two_step):
     plane_full = PH * M * C64
     plane_h = h * M * C64
     img = w * h
+    if fused_plan(w, h):
+        # fused kernels: u8 <-> full half-plane in one launch; the H x M intermediate never exists
+        if stage == "rows_fwd":
+            return 3 * img + 3 * plane_full
+        if stage == "rows_inv":
+            return 3 * plane_full + 3 * img
+        if stage in ("cols_fwd_a", "cols_inv_b"):
+            return 0
     return {
         "rows_fwd": 3 * img + 3 * plane_h,
         "cols_fwd_a": 3 * plane_h + 3 * plane_full,
@@ -220,6 +234,8 @@ def main():
             kb = kernel_bytes(name, W, H, n_bits, two_step) * slots
             stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots, "kernel_bytes": kb,
                             "GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+            if fused_plan(W, H) and name in ("rows_fwd", "rows_inv"):
+                stages[name]["kernel"] = "k_rowcol_fwd (rows + column step A)" if name == "rows_fwd" else "k_colrow_inv (column step B' + rows)"
         fft_stages = {k: v for k, v in stages.items() if k.startswith(("rows", "cols"))}
         dom = max(fft_stages, key=lambda k: fft_stages[k]["ms"])
         d = stages[dom]

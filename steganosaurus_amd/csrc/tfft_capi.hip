@@ -28,7 +28,7 @@ struct Slot {     // geometry of one resident image; its buffers are slices of t
     bool has_spec = false;
 };
 
-struct ColPlan { bool direct; int log_n1, log_n2; };
+struct ColPlan { bool direct; int log_n1, log_n2; bool fused_fwd; };
 
 }  // namespace
 
@@ -62,6 +62,7 @@ struct tfft_ctx {
     int cols_tiles_per_block = 8;
     int rows_per_block = 8;
     int median_force_fallback = 0;
+    int fuse = 1;
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
     float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
@@ -99,9 +100,15 @@ int get_twiddles(tfft_ctx* c, int n, const float2** out) {
     return TFFT_OK;
 }
 
-ColPlan plan_cols(const tfft_ctx* c, int PH) {
+ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi = 0) {
     const int l = ilog2i(PH);
     ColPlan p;
+    p.fused_fwd = false;
+    if (c->fuse && PWi == 2048 && l >= 7 && l - 3 <= 10 && c->cols_force_log_n1 < 0) {
+        // rows + first column step in one kernel (k_rowcol_fwd): PH = 8 * N2
+        p.direct = false; p.log_n1 = 3; p.log_n2 = l - 3; p.fused_fwd = true;
+        return p;
+    }
     if (l <= c->cols_direct_max_log && c->cols_force_log_n1 < 0) { p.direct = true; p.log_n1 = 0; p.log_n2 = l; return p; }
     p.direct = false;
     int l1 = (c->cols_force_log_n1 >= 0) ? c->cols_force_log_n1 : l / 2;
@@ -135,7 +142,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     const float2 *tw_w, *tw_h;
     int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
     rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
-    const ColPlan pl = plan_cols(c, s.PH);
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi);
     const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
     float2 *spec = c->spec(s0), *tmp = c->tmp(s0);
     ColParams cp{};
@@ -144,10 +151,12 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     switch (stage) {
         case ROWS_FWD: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->rows_per_block, n};
-            HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
+            if (pl.fused_fwd) HIPCHK(c, launch_rowcol_fwd(rgb_in, tmp, tw_w, tw_h, rp, n, st));   // rows + column step A
+            else HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
             return TFFT_OK;
         }
         case COLS_FWD_A:
+            if (pl.fused_fwd) return TFFT_OK;       // done inside ROWS_FWD
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
@@ -172,14 +181,15 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             }
             return TFFT_OK;
         case COLS_INV_B:
-            if (pl.direct) return TFFT_OK;
+            if (pl.direct || pl.fused_fwd) return TFFT_OK;      // fused: done inside ROWS_INV
             // for every n2: length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
             cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
             HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->rows_per_block, n};
-            HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
+            if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
+            else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
         }
         default: return TFFT_E_INVALID;
@@ -305,6 +315,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->device = device; c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots;
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
+    if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_ROWS_PER_BLOCK")) c->rows_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
@@ -581,9 +592,10 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     const Slot& s = c->slots[0];
     if (s.PH == 0) return TFFT_E_STATE;
     for (int i = 1; i < n_images; i++) c->slots[i] = s;
-    const ColPlan pl = plan_cols(c, s.PH);
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi);
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
+    if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
     if (stage == MEDIANS) launches = c->median_force_fallback ? 7 : 13;
     if (stage == CAPACITY) launches = 2;
     if (n_launches) *n_launches = launches;

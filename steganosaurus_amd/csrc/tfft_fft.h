@@ -188,6 +188,57 @@ __device__ __forceinline__ void fft_block(float2 (&u)[E], float2* lds, const Lay
     if constexpr (N > 1) FftPasses<N, E, SIGN, 1, 0, TOT, Lay, Sync>::run(u, lds, lay, t, b, W);
 }
 
+// Same passes with the twiddles read from the table at the point of use (no register prefetch): for
+// kernels whose occupancy is limited by VGPRs rather than by table latency.
+template <int N, int E, int SIGN, int P, class Lay, class Sync>
+struct FftPassesLazy {
+    static constexpr int R = imin(E, N / P);
+    static constexpr bool LAST = (P * R == N);
+    static constexpr int T = N / E;
+    static constexpr int Q = E / R;
+    static __device__ __forceinline__ void run(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
+                                               const float2* __restrict__ tw, int tws) {
+        float2 o[E];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) v[r] = u[q + r * Q];
+            const int i = t + q * T;
+            const int k = i & (P - 1);
+            if constexpr (P > 1) {
+                const int base = k * (N / (P * R)) * tws;
+#pragma unroll
+                for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
+            }
+            DftReg<R, SIGN, 0, R>::run(v);
+            if constexpr (LAST) {
+#pragma unroll
+                for (int s = 0; s < R; s++) o[q + s * Q] = v[bitrev(s, ilog2(R))];
+            } else {
+                const int j = (i - k) * R + k;
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[lay.idx(j + s * P, b)] = v[bitrev(s, ilog2(R))];
+            }
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = o[m];
+        } else {
+            Sync::sync();
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, b)];
+            Sync::sync();
+            FftPassesLazy<N, E, SIGN, P * R, Lay, Sync>::run(u, lds, lay, t, b, tw, tws);
+        }
+    }
+};
+template <int N, int E, int SIGN, class Sync = BlockSync, class Lay>
+__device__ __forceinline__ void fft_block_lazy(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
+                                               const float2* __restrict__ tw, int tws) {
+    if constexpr (N > 1) FftPassesLazy<N, E, SIGN, 1, Lay, Sync>::run(u, lds, lay, t, b, tw, tws);
+}
+
 // elements per thread for a length-N transform
 constexpr int elems_for(int n) { return imin(16, n); }
 

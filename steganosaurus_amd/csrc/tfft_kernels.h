@@ -67,6 +67,9 @@ struct SelectState {        // one per (image, plane)
 
 hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s);
+hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
+                             int n_images, hipStream_t s);
+hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s);
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s);
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,

@@ -158,6 +158,99 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
     }
 }
 
+// ---------------------------------------------------------------------------
+// rows + first column step, fused (images up to 2048 wide, PH = N1*N2 with N1 = 8):
+// a workgroup holds the N1 rows y = n1*N2 + n2 of one plane in LDS, one wave per row.
+// Each wave does the real FFT of its row exactly like k_rows_fwd (rows >= H are zero
+// and skipped), the workgroup then takes the length-N1 DFT across the rows for every
+// column, multiplies by w^(n2*k1) and stores rows k1*N2 + n2: the result is what
+// k_rows_fwd followed by the first k_fft_cols step leaves in `out`, without writing
+// and re-reading the H x M intermediate.
+//   grid (N2, 3, n_images)   block (64, N1)   M = 1024, E = 16
+// ---------------------------------------------------------------------------
+template <int LOGN1>
+__global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out,
+                             const float2* __restrict__ tw, const float2* __restrict__ tw_h, RowParams P) {
+    constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
+    const int t = threadIdx.x, n1 = threadIdx.y;
+    const int N2 = P.PH >> LOGN1;
+    const int n2 = blockIdx.x, plane = blockIdx.y, img = blockIdx.z;
+    const int y = n1 * N2 + n2;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+    const bool live = y < P.H;          // wave uniform: a row is exactly one wave
+
+    if (live) {
+        const int nbytes = P.W * 3;
+        const uint8_t* src = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
+        if (((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0)) {
+            const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+            const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
+            const int sh = 8 * plane;
+            for (int g = t; g < (P.W >> 2); g += T) {
+                const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];
+                const uint64_t lo = ((uint64_t)b << 32) | a, hi = ((uint64_t)c << 32) | b;
+                lds[lay.idx(2 * g, n1)] = make_float2(s0 * (float)((lo >> sh) & 0xFF), s1 * (float)((lo >> (sh + 24)) & 0xFF));
+                lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * (float)((hi >> (sh + 16)) & 0xFF), s1 * (float)((hi >> (sh + 40)) & 0xFF));
+            }
+            for (int m = (P.W >> 1) + t; m < M; m += T) lds[lay.idx(m, n1)] = make_float2(0.f, 0.f);
+        } else {
+            for (int n = t; n < 2 * M; n += T) {
+                float v = 0.0f;
+                if (n < P.W) { v = (float)src[3 * n + plane]; if (P.center && ((n + y) & 1)) v = -v; }
+                ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
+            }
+        }
+        WaveSync::sync();
+        float2 u[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+        WaveSync::sync();
+        fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, tw, 2);
+#pragma unroll
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];
+        WaveSync::sync();
+        // split in place: the pair (k, M-k) is read and rewritten by the same thread
+#pragma unroll
+        for (int j = 0; j < (M / 2) / T + 1; j++) {
+            const int k = t + j * T;
+            if (k > M / 2) break;
+            const int k2 = (M - k) & (M - 1);
+            const float2 zk = lds[lay.idx(k, n1)], zm = lds[lay.idx(k2, n1)];
+            const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);
+            const float2 b = cmul(tw[k], od);
+            if (k == 0) {
+                lds[lay.idx(0, n1)] = make_float2(a.x + b.x, a.x - b.x);
+            } else {
+                lds[lay.idx(k, n1)] = cadd(a, b);
+                if (k2 != k) lds[lay.idx(k2, n1)] = cconj(csub(a, b));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+
+    // ---- length-N1 DFT across the rows, per column; output row k1*N2 + n2, times exp(+2 pi i n2 k1/PH)
+    float2 wc[N1];
+#pragma unroll
+    for (int k1 = 0; k1 < N1; k1++) wc[k1] = tw_h[(n2 * k1) & (P.PH - 1)];
+    float2* dst = out + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
+    for (int x = n1 * T + t; x < M; x += T * N1) {
+        float2 v[N1];
+#pragma unroll
+        for (int r = 0; r < N1; r++) v[r] = lds[lay.idx(x, r)];
+        DftReg<N1, +1, 0, N1>::run(v);
+#pragma unroll
+        for (int k1 = 0; k1 < N1; k1++)
+            dst[(size_t)k1 * N2 * M + x] = cmul(v[bitrev(k1, LOGN1)], wc[k1]);
+    }
+}
+
 // clamp(round(v), 0, 255) with C round() semantics (half away from zero, S:389) for the values that
 // survive the clamp: negatives go to 0 either way, so only v >= 0 needs exact half-up rounding
 // (v - trunc(v) is exact in fp32, unlike v + 0.5f).
@@ -165,6 +258,79 @@ __device__ __forceinline__ unsigned quantise_u8(float v) {
     v = fminf(fmaxf(v, 0.0f), 255.0f);
     const float r = truncf(v);
     return (unsigned)r + ((v - r >= 0.5f) ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------
+// last inverse column step + rows, fused (mirror image of k_rowcol_fwd): for every
+// column the length-N1 inverse DFT across the rows k1*N2 + n2 gives the rows
+// n1*N2 + n2 in LDS; one wave per row then does the half-spectrum -> real row
+// transform, scales, rounds and stores its plane's bytes.  Rows >= H are dropped.
+// Replaces the second k_fft_cols inverse step followed by k_rows_inv.
+//   grid (N2, 3, n_images)   block (64, N1)   M = 1024, E = 16
+// ---------------------------------------------------------------------------
+template <int LOGN1>
+__global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
+                             const float2* __restrict__ tw, RowParams P) {
+    constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
+    const int t = threadIdx.x, n1 = threadIdx.y;
+    const int N2 = P.PH >> LOGN1;
+    const int n2 = blockIdx.x, plane = blockIdx.y, img = blockIdx.z;
+    const int y = n1 * N2 + n2;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+
+    // ---- length-N1 inverse DFT across the rows, per column
+    const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
+    for (int x = n1 * T + t; x < M; x += T * N1) {
+        float2 v[N1];
+#pragma unroll
+        for (int k1 = 0; k1 < N1; k1++) v[k1] = src[(size_t)k1 * N2 * M + x];
+        DftReg<N1, -1, 0, N1>::run(v);
+#pragma unroll
+        for (int r = 0; r < N1; r++) lds[lay.idx(x, r)] = v[bitrev(r, LOGN1)];
+    }
+    __syncthreads();
+    if (y >= P.H) return;               // wave uniform (one wave per row); no barrier follows
+
+    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
+    float2 u[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) {
+        const int k = t + m * T;
+        const float2 xk = lds[lay.idx(k, n1)];
+        if (k == 0) {
+            u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));
+        } else {
+            const float2 xm = lds[lay.idx(M - k, n1)];
+            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 od = cmul(d, cconj(tw[k]));
+            u[m] = make_float2(ev.x - od.y, ev.y + od.x);
+        }
+    }
+    WaveSync::sync();
+    fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, tw, 2);
+#pragma unroll
+    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
+    WaveSync::sync();
+
+    // ---- quantise and store this plane's bytes of row y
+    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
+    if ((P.W & 1) == 0) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+        for (int m = t; m < (P.W >> 1); m += T) {
+            const float2 v = lds[lay.idx(m, n1)];
+            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x);
+            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y);
+        }
+    } else {
+        for (int n = t; n < P.W; n += T) {
+            float v = ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)];
+            if (P.center && ((n + y) & 1)) v = -v;
+            dst[3 * n] = (uint8_t)quantise_u8(v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -820,6 +986,25 @@ hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw,
     TFFT_DISPATCH_LOG(logm, F)
 #undef F
     return hipSuccess;
+}
+hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
+                             int n_images, hipStream_t s) {
+    constexpr int LOGN1 = 3;
+    const size_t lds = (size_t)(1 << LOGN1) * LayRows::padded(1024) * sizeof(float2);
+    auto k = k_rowcol_fwd<LOGN1>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(P.PH >> LOGN1, 3, n_images), dim3(64, 1 << LOGN1), lds, s, rgb, out, tw_pw, tw_ph, P);
+    return hipGetLastError();
+}
+hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
+    constexpr int LOGN1 = 3;
+    const size_t lds = (size_t)(1 << LOGN1) * LayRows::padded(1024) * sizeof(float2);
+    auto k = k_colrow_inv<LOGN1>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(P.PH >> LOGN1, 3, n_images), dim3(64, 1 << LOGN1), lds, s, in, rgb, tw_pw, P);
+    return hipGetLastError();
 }
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s) {

@@ -46,6 +46,12 @@ def test_median_fast_and_fallback_paths(emu, orc):
     PC.check_median_paths(emu, orc, [(64, 64), (48, 40), (8, 4), (128, 32)])
 
 
+def test_fused_rows_plus_column_step(emu, orc):
+    # PW = 2048 and PH >= 128: k_rowcol_fwd (rows + length-8 column step in one kernel), then step B
+    PC.check_forward_against_oracle(emu, orc, [(1500, 130), (2047, 129)], centers=(0, 1))
+    PC.check_identity_roundtrip(emu, [(1500, 130)])
+
+
 def test_identity_roundtrip(emu):
     PC.check_identity_roundtrip(emu, [(64, 64), (48, 40), (33, 17), (2, 2), (1, 1), (5, 1), (1, 7), (12, 1024)])
 
