@@ -181,6 +181,12 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     LayRows lay{LayRows::padded(M)};
     const bool live = y < P.H;          // wave uniform: a row is exactly one wave
 
+    constexpr int NSPLIT = (M / 2) / T + 1;
+    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW): lane-only indices, fetched before the staging
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
+    }
     if (live) {
         const int nbytes = P.W * 3;
         const uint8_t* src = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
         WaveSync::sync();
         // split in place: the pair (k, M-k) is read and rewritten by the same thread
 #pragma unroll
-        for (int j = 0; j < (M / 2) / T + 1; j++) {
+        for (int j = 0; j < NSPLIT; j++) {
             const int k = t + j * T;
             if (k > M / 2) break;
             const int k2 = (M - k) & (M - 1);
@@ -221,7 +227,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
             const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
             const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
             const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);
-            const float2 b = cmul(tw[k], od);
+            const float2 b = cmul(wk[j], od);
             if (k == 0) {
                 lds[lay.idx(0, n1)] = make_float2(a.x + b.x, a.x - b.x);
             } else {
@@ -305,7 +311,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
             const float2 xm = lds[lay.idx(M - k, n1)];
             const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
             const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(tw[k]));
+            const float2 od = cmul(d, cconj(tw[k]));      // fetched here: prefetching 16 more registers costs a workgroup per CU
             u[m] = make_float2(ev.x - od.y, ev.y + od.x);
         }
     }
