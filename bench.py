@@ -253,6 +253,25 @@ def main():
                                   "HIP events on the launch stream, %d back-to-back launches" % args.stage_reps}
         out["stages"] = stages
 
+        if world == 1:
+            # side figure, never `value`: the same step when the caller hands over HOST buffers
+            # (pinned memory, H2D of the covers + D2H of stego and bits over PCIe inside the timed region)
+            h_img = torch.from_numpy(covers).pin_memory()
+            h_stego = torch.empty(d_stego.shape, dtype=torch.uint8).pin_memory()
+            h_raw = torch.empty(d_raw.shape, dtype=torch.uint8).pin_memory()
+            def host_step():
+                d_img.copy_(h_img, non_blocking=True)
+                step()
+                h_stego.copy_(d_stego, non_blocking=True)
+                h_raw.copy_(d_raw, non_blocking=True)
+            host_step(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                host_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            out["pcie_inclusive"] = {"value": round(n_img * W * H / dt / 1e6, 1), "unit": "MPixels/s", "ms_per_step": round(dt * 1e3, 3),
+                                     "note": "pinned host buffers; H2D covers + D2H stego and raw bits inside the timed region; not overlapped"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, secret, n_bits, covers[0], bits[0])
         print(json.dumps(out))
