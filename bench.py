@@ -113,10 +113,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    # rehearsal knobs for a one-GPU box: TFFT_BENCH_BACKEND=gloo runs the collectives on CPU copies and
+    # TFFT_BENCH_SHARE_GPU=1 puts every rank on GPU 0 (the driver's multi-GPU runs use neither)
+    backend = os.environ.get("TFFT_BENCH_BACKEND", "nccl")
+    if os.environ.get("TFFT_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     W, H, secret, n_img, wl_desc = WORKLOADS[args.workload]
     if args.images > 0:
@@ -145,7 +154,13 @@ def main():
         t_walk = time.time() - t0
         d_bins.copy_(torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()))
     if world > 1:
-        dist.broadcast(d_bins, src=0)           # the only collective: 8 B x n_bits over xGMI, before the timed region
+        # the only collective: 8 B x n_bits over xGMI, before the timed region
+        if backend == "nccl":
+            dist.broadcast(d_bins, src=0)
+        else:
+            hb = d_bins.cpu()
+            dist.broadcast(hb, src=0)
+            d_bins.copy_(hb)
     d_stego = torch.empty_like(d_img)
     d_raw = torch.empty((n_img, n_bits), dtype=torch.uint8, device=dev)
     d_usable = torch.zeros(n_img, dtype=torch.int64, device=dev)
@@ -176,7 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctx.sync()
