@@ -213,6 +213,8 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
         WaveSync::sync();
+        // pass twiddles are read at the point of use: prefetching them (54 more VGPRs) leaves room for one
+        // workgroup per CU instead of two and measured 0.87 ms against 0.66 ms per 32-image launch
         fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, tw, 2);
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];

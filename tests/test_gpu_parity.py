@@ -206,6 +206,37 @@ def test_pow2_companion_full_payload_recovery(lib, orc, size, secret):
     ctx.close()
 
 
+def test_config5_8192_roundtrip(lib, orc):
+    """BASELINE configs[4]: 8192x8192, 128 KB payload (7 341 840 stream bits): host walk, capacity, embed,
+    inverse, forward, read; every payload bit recovered after Rep-3/Rep-7; forward->inverse is the identity."""
+    size, secret = 8192, 131072
+    n = n_stream_bits(secret)
+    assert n == 7341840
+    rng = np.random.default_rng(8192)
+    hdr = rng.integers(0, 2, 38 * 8).astype(np.uint8)
+    pay = rng.integers(0, 2, (secret + 16) * 8).astype(np.uint8)
+    bits = _rep_encode(pay, hdr)
+    img = cover_rgb(size, size, 0)
+    wk = B.Walk(orc.subkeys(PC.PK)[0], size, size, lib=lib)
+    bins = wk.next(n)
+    ctx = B.Context(size, size, lib=lib)
+    ctx.forward_rgb8(img)
+    back = ctx.inverse_rgb8(size, size)
+    assert np.array_equal(back, img)
+    ctx.forward_rgb8(img)
+    med = ctx.medians()
+    assert ctx.median_path().sum() == 3
+    assert ctx.capacity(0.01 * med) >= n
+    ctx.embed_bins(bins, bits)
+    stego = ctx.inverse_rgb8(size, size)
+    ctx.forward_rgb8(stego)
+    raw = ctx.read_bins(bins)
+    assert float((raw != bits).mean()) < 0.02
+    assert np.array_equal((raw[:912].reshape(-1, 3).sum(1) >= 2).astype(np.uint8), hdr)
+    assert np.array_equal((raw[912:].reshape(-1, 7).sum(1) >= 4).astype(np.uint8), pay)
+    ctx.close()
+
+
 def test_batch_matches_single(lib, orc):
     """tfft_embed_batch_dev / tfft_extract_batch_dev == the single-image calls, image by image."""
     import torch
