@@ -146,6 +146,19 @@ int tfft_embed_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w
 int tfft_extract_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
                            const void* bins_dev, uint64_t n_bits, double alpha, void* bits_out_dev);
 
+/* The same two pipelines for HOST buffers (images packed back to back, one byte per bit): the slots
+ * are split into two halves and three HIP streams overlap the PCIe copy-in of the next half-batch,
+ * the kernels of the current one and the copy-out of the previous one.  The
+ * transfers overlap only when the host buffers are page-locked: tfft_host_alloc / tfft_host_free, or
+ * any pinned allocation.  Both calls return after the last result has landed. */
+int tfft_embed_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                     const uint8_t* bits, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                     uint64_t* usable_out /* or NULL */, uint8_t* rgb_out);
+int tfft_extract_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                       uint64_t n_bits, double alpha, uint8_t* bits_out);
+void* tfft_host_alloc(size_t bytes);
+void tfft_host_free(void* p);
+
 /* --------------------------------------------------------- keyed walk (HOST)
  * KS + Turtle + the density gate (S:665-695, S:749-810, S:1076-1081): a
  * resumable generator of embedding positions.  Pure host code, no device.

@@ -48,6 +48,10 @@ SYMBOLS = {
     "tfft_download_spectrum": (_i, [_vp, _i, _vp]),
     "tfft_embed_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
     "tfft_extract_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
+    "tfft_embed_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
+    "tfft_extract_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
+    "tfft_host_alloc": (_vp, [C.c_size_t]),
+    "tfft_host_free": (None, [_vp]),
     "tfft_walk_create": (_i, [C.c_char_p, _i, _i, _d, _d, _d, C.POINTER(_vp)]),
     "tfft_walk_next": (_i, [_vp, _u64, _vp, C.POINTER(_u64)]),
     "tfft_walk_start": (_i, [_vp, _pi, _pi, _pi]),
@@ -279,6 +283,18 @@ class Context:
                                            _ptr(bits_ptr), _ptr(bits_out_ptr), n_bits, alpha, C.byref(ms),
                                            C.byref(nl)), "tfft_profile_stage")
         return ms.value, nl.value
+
+    def embed_batch_host(self, rgb, bins, bits, out, usable=None, alpha=0.5, center=False, rmin=0.05, rmax=0.45,
+                         magmin=0.01):
+        """rgb/out: (n,H,W,3) uint8 host arrays (pinned for overlap); bits: (n,n_bits) uint8."""
+        n, h, w = rgb.shape[:3]
+        _check(self.lib.tfft_embed_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), _ptr(bits), bits.shape[1], alpha,
+                                         rmin, rmax, magmin, _ptr(usable), _ptr(out)), "tfft_embed_batch")
+
+    def extract_batch_host(self, rgb, bins, bits_out, alpha=0.5, center=False):
+        n, h, w = rgb.shape[:3]
+        _check(self.lib.tfft_extract_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), bits_out.shape[1], alpha,
+                                           _ptr(bits_out)), "tfft_extract_batch")
 
     def timer_begin(self):
         _check(self.lib.tfft_timer_begin(self.h), "tfft_timer_begin")

@@ -57,6 +57,9 @@ struct tfft_ctx {
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    uint8_t* out_pool = nullptr;
     int cols_direct_max_log = 9;          // PH <= 512: one column pass; taller: two-step N1 x N2
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
@@ -353,6 +356,10 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
+    (void)hipFree(c->out_pool);
+    for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -541,6 +548,34 @@ static int batch_geometry(tfft_ctx* c, int g, int w, int h, int center) {
     return TFFT_OK;
 }
 
+// one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
+static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
+                       uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st) {
+    const Slot& s = c->slots[s0];
+    int rc = enqueue_forward(c, s0, g, rgb_in, st);
+    if (rc) return rc;
+    if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip
+        rc = enqueue_medians(c, s0, g, st);
+        if (rc) return rc;
+        CapParams p = cap_params(c, s, rmin, rmax);
+        p.magmin = magmin;
+        HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)3 * s0 * TFFT_STAT_MAX_BLOCKS, usable, st));
+    }
+    EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+    HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
+    return enqueue_inverse(c, s0, g, rgb_out, st);
+}
+static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, uint64_t n_bits,
+                         double alpha, uint8_t* bits_out, hipStream_t st) {
+    const Slot& s = c->slots[s0];
+    int rc = enqueue_forward(c, s0, g, rgb_in, st);
+    if (rc) return rc;
+    EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+    HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
+    return TFFT_OK;
+}
+
 int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
                          const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
                          void* usable_out_dev, void* rgb_out_dev) {
@@ -550,19 +585,10 @@ int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, 
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
         int rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        const Slot& s = c->slots[0];
-        rc = enqueue_forward(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, c->stream);
-        if (rc) return rc;
-        if (usable_out_dev) {      // S:922-923, S:998-1012 on the device, no host round trip
-            rc = enqueue_medians(c, 0, g, c->stream);
-            if (rc) return rc;
-            CapParams p = cap_params(c, s, rmin, rmax);
-            p.magmin = magmin;
-            HIPCHK(c, launch_capacity(c->spec(0), p, g, c->med, c->partial, (unsigned long long*)usable_out_dev + i0, c->stream));
-        }
-        EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
-        HIPCHK(c, launch_embed(c->spec(0), (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev + (size_t)i0 * n_bits, nullptr, ep, g, c->err, c->stream));
-        rc = enqueue_inverse(c, 0, g, (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes, c->stream);
+        rc = embed_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev,
+                         (const uint8_t*)bits_dev + (size_t)i0 * n_bits, n_bits, alpha, rmin, rmax, magmin,
+                         usable_out_dev ? (unsigned long long*)usable_out_dev + i0 : nullptr,
+                         (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes, c->stream);
         if (rc) return rc;
     }
     return TFFT_OK;
@@ -576,14 +602,96 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
         int rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        const Slot& s = c->slots[0];
-        rc = enqueue_forward(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, c->stream);
+        rc = extract_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, n_bits, alpha,
+                           (uint8_t*)bits_out_dev + (size_t)i0 * n_bits, c->stream);
         if (rc) return rc;
-        EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
-        HIPCHK(c, launch_read(c->spec(0), (const tfft_bin*)bins_dev, nullptr, ep, g, (uint8_t*)bits_out_dev + (size_t)i0 * n_bits, c->err, c->stream));
     }
     return TFFT_OK;
 }
+
+// ---------------------------------------------------------------- host-buffer batches
+// The slots are split into two halves; while one half computes, the other half's inputs arrive over
+// PCIe on a copy-in stream and the previous results leave on a copy-out stream.  Overlap needs pinned
+// host memory (tfft_host_alloc or any page-locked buffer); pageable buffers work but serialise.
+static int pipe_init(tfft_ctx* c) {
+    if (c->s_in) return TFFT_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+    }
+    return dev_alloc(c, (void**)&c->out_pool, (size_t)c->n_slots * c->img_stride_b + 256);
+}
+
+static int batch_host(tfft_ctx* c, bool embed, int n_images, const uint8_t* rgb, int w, int h, int center,
+                      const tfft_bin* bins, const uint8_t* bits, uint64_t n_bits, double alpha, double rmin, double rmax,
+                      double magmin, uint64_t* usable, uint8_t* rgb_out, uint8_t* bits_out) {
+    if (n_images == 0) return TFFT_OK;
+    int rc = pipe_init(c);
+    if (rc) return rc;
+    rc = ensure_stage(c, (uint64_t)c->n_slots * n_bits > n_bits ? (uint64_t)c->n_slots * n_bits : n_bits);
+    if (rc) return rc;
+    rc = batch_geometry(c, c->n_slots, w, h, center);
+    if (rc) return rc;
+    { const float2* t; rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
+    const size_t img_bytes = (size_t)w * h * 3;
+    const int half = c->n_slots >= 2 ? c->n_slots / 2 : 1;
+    const int nhalves = c->n_slots >= 2 ? 2 : 1;
+    HIPCHK(c, hipMemcpyAsync(c->stage_bins, bins, n_bits * sizeof(tfft_bin), hipMemcpyHostToDevice, c->stream));
+    int chunk = 0;
+    for (int i0 = 0; i0 < n_images; i0 += half, chunk++) {
+        const int g = (n_images - i0 < half) ? n_images - i0 : half;
+        const int hh = chunk % nhalves, s0 = hh * half;
+        uint8_t* d_bits = (uint8_t*)c->stage_bits + (size_t)s0 * n_bits;
+        uint8_t* d_bout = (uint8_t*)c->stage_out + (size_t)s0 * n_bits;
+        // copy-in: the half's input buffers are free once the chunk that used them has been computed
+        HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_comp[hh], 0));
+        // the pipeline treats the half's staging area as one packed batch buffer (g images back to back)
+        HIPCHK(c, hipMemcpyAsync(c->img(s0), rgb + (size_t)i0 * img_bytes, (size_t)g * img_bytes, hipMemcpyHostToDevice, c->s_in));
+        if (embed) HIPCHK(c, hipMemcpyAsync(d_bits, bits + (size_t)i0 * n_bits, (size_t)g * n_bits, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipEventRecord(c->ev_in[hh], c->s_in));
+        // compute: needs the inputs, and the half's output buffers drained by the copy-out of two chunks ago
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[hh], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[hh], 0));
+        if (embed)
+            rc = embed_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, d_bits, n_bits, alpha, rmin, rmax, magmin,
+                             usable ? c->usable + s0 : nullptr, c->out_pool + (size_t)s0 * c->img_stride_b, c->stream);   // packed, like the input
+        else
+            rc = extract_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, n_bits, alpha, d_bout, c->stream);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_comp[hh], c->stream));
+        // copy-out
+        HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_comp[hh], 0));
+        if (embed) {
+            HIPCHK(c, hipMemcpyAsync(rgb_out + (size_t)i0 * img_bytes, c->out_pool + (size_t)s0 * c->img_stride_b, (size_t)g * img_bytes, hipMemcpyDeviceToHost, c->s_out));
+            if (usable) HIPCHK(c, hipMemcpyAsync(usable + i0, c->usable + s0, (size_t)g * sizeof(uint64_t), hipMemcpyDeviceToHost, c->s_out));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(bits_out + (size_t)i0 * n_bits, d_bout, (size_t)g * n_bits, hipMemcpyDeviceToHost, c->s_out));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_out[hh], c->s_out));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_out));
+    return check_err_flag(c);
+}
+
+int tfft_embed_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                     const uint8_t* bits, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                     uint64_t* usable_out, uint8_t* rgb_out) {
+    if (!c || n_images < 0 || !rgb || !rgb_out || !bins || !bits || n_bits == 0) return TFFT_E_INVALID;
+    return batch_host(c, true, n_images, rgb, w, h, center, bins, bits, n_bits, alpha, rmin, rmax, magmin, usable_out, rgb_out, nullptr);
+}
+int tfft_extract_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                       uint64_t n_bits, double alpha, uint8_t* bits_out) {
+    if (!c || n_images < 0 || !rgb || !bins || !bits_out || n_bits == 0) return TFFT_E_INVALID;
+    return batch_host(c, false, n_images, rgb, w, h, center, bins, nullptr, n_bits, alpha, 0, 0, 0, nullptr, nullptr, bits_out);
+}
+void* tfft_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes, 0) == hipSuccess ? p : nullptr;
+}
+void tfft_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
                        const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,

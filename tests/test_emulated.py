@@ -128,3 +128,26 @@ def test_unaligned_device_pointers(emu):
         assert np.array_equal(outraw[off:off + img.size].reshape(h, w, 3), img), (w, h, off)
         assert outraw[:off].sum() == 0 and outraw[off + img.size:].sum() == 0      # nothing written outside
         ctx.close()
+
+
+def test_host_batch_pipeline_matches_device_batch(emu, orc):
+    """tfft_embed_batch / tfft_extract_batch (double-buffered halves, copy streams) == the resident-batch calls."""
+    from steganosaurus_amd.synth import cover_rgb
+    w, h, nimg, n = 40, 24, 7, 100
+    imgs = np.stack([cover_rgb(w, h, i) for i in range(nimg)])
+    bits = np.random.default_rng(3).integers(0, 2, (nimg, n)).astype(np.uint8)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], orc.next_pow2(h), orc.next_pow2(w), lib=emu).next(n)
+    ref_out = np.zeros_like(imgs); ref_raw = np.zeros((nimg, n), np.uint8); ref_us = np.zeros(nimg, np.uint64)
+    ctx = B.Context(w, h, slots=4, lib=emu)
+    ctx.embed_batch_dev(nimg, imgs.ctypes.data, w, h, bins.ctypes.data, bits.ctypes.data, n, ref_out.ctypes.data,
+                        usable_ptr=ref_us.ctypes.data)
+    ctx.extract_batch_dev(nimg, ref_out.ctypes.data, w, h, bins.ctypes.data, n, ref_raw.ctypes.data)
+    ctx.sync()
+    for slots in (4, 1, 3):
+        c2 = B.Context(w, h, slots=slots, lib=emu)
+        out = np.zeros_like(imgs); raw = np.zeros((nimg, n), np.uint8); us = np.zeros(nimg, np.uint64)
+        c2.embed_batch_host(imgs, bins, bits, out, usable=us)
+        c2.extract_batch_host(out, bins, raw)
+        assert np.array_equal(out, ref_out) and np.array_equal(raw, ref_raw) and np.array_equal(us, ref_us), slots
+        c2.close()
+    ctx.close()

@@ -273,3 +273,38 @@ def test_batch_matches_single(lib, orc):
         one.forward_rgb8(st)
         assert np.array_equal(one.read_bins(bins), raw[i]), i
     one.close(); ctx.close()
+
+
+def test_host_batch_pipeline(lib, orc):
+    """Host-buffer batches through pinned memory and the three-stream pipeline == resident batches."""
+    import ctypes as C
+    import torch
+    w, h, nimg, secret = 640, 360, 9, 64
+    n = n_stream_bits(secret)
+    imgs = np.stack([cover_rgb(w, h, i) for i in range(nimg)])
+    bits = np.random.default_rng(4).integers(0, 2, (nimg, n)).astype(np.uint8)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], orc.next_pow2(h), orc.next_pow2(w), lib=lib).next(n)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev); d_bits = torch.from_numpy(bits).to(dev)
+    d_bins = torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()).to(dev)
+    d_out = torch.empty_like(d_img); d_raw = torch.empty((nimg, n), dtype=torch.uint8, device=dev)
+    d_us = torch.zeros(nimg, dtype=torch.int64, device=dev)
+    ctx = B.Context(w, h, slots=4, lib=lib)
+    ctx.embed_batch_dev(nimg, d_img.data_ptr(), w, h, d_bins.data_ptr(), d_bits.data_ptr(), n, d_out.data_ptr(), usable_ptr=d_us.data_ptr())
+    ctx.extract_batch_dev(nimg, d_out.data_ptr(), w, h, d_bins.data_ptr(), n, d_raw.data_ptr())
+    ctx.sync()
+    # pinned host buffers from the library's own allocator
+    nb = imgs.nbytes
+    p_in = lib.tfft_host_alloc(nb); p_out = lib.tfft_host_alloc(nb)
+    assert p_in and p_out
+    a_in = np.ctypeslib.as_array((C.c_uint8 * nb).from_address(p_in)).reshape(imgs.shape)
+    a_out = np.ctypeslib.as_array((C.c_uint8 * nb).from_address(p_out)).reshape(imgs.shape)
+    a_in[...] = imgs
+    us = np.zeros(nimg, np.uint64); raw = np.zeros((nimg, n), np.uint8)
+    ctx.embed_batch_host(a_in, bins, bits, a_out, usable=us)
+    ctx.extract_batch_host(a_out, bins, raw)
+    assert np.array_equal(a_out, d_out.cpu().numpy())
+    assert np.array_equal(raw, d_raw.cpu().numpy())
+    assert np.array_equal(us.astype(np.int64), d_us.cpu().numpy())
+    lib.tfft_host_free(p_in); lib.tfft_host_free(p_out)
+    ctx.close()
