@@ -58,7 +58,7 @@ struct tfft_ctx {
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipEvent_t ev_in[4] = {}, ev_comp[4] = {}, ev_out[4] = {};
     uint8_t* out_pool = nullptr;
     int cols_direct_max_log = 9;          // PH <= 512: one column pass; taller: two-step N1 x N2
     int cols_force_log_n1 = -1;
@@ -357,7 +357,7 @@ int tfft_destroy(tfft_ctx* c) {
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
     (void)hipFree(c->out_pool);
-    for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
+    for (int i = 0; i < 4; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -610,14 +610,14 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
 }
 
 // ---------------------------------------------------------------- host-buffer batches
-// The slots are split into two halves; while one half computes, the other half's inputs arrive over
-// PCIe on a copy-in stream and the previous results leave on a copy-out stream.  Overlap needs pinned
+// The slots are split into a ring of up to four parts; while one part computes, the next parts' inputs
+// arrive over PCIe on a copy-in stream and earlier results leave on a copy-out stream.  Overlap needs pinned
 // host memory (tfft_host_alloc or any page-locked buffer); pageable buffers work but serialise.
 static int pipe_init(tfft_ctx* c) {
     if (c->s_in) return TFFT_OK;
     HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 4; i++) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
@@ -637,8 +637,9 @@ static int batch_host(tfft_ctx* c, bool embed, int n_images, const uint8_t* rgb,
     if (rc) return rc;
     { const float2* t; rc = get_twiddles(c, c->slots[0].PWi, &t); if (rc) return rc; rc = get_twiddles(c, c->slots[0].PH, &t); if (rc) return rc; }
     const size_t img_bytes = (size_t)w * h * 3;
-    const int half = c->n_slots >= 2 ? c->n_slots / 2 : 1;
-    const int nhalves = c->n_slots >= 2 ? 2 : 1;
+    // the slots form a ring of up to four parts: copy-in of part k+1..k+3 overlaps the kernels of part k
+    const int nhalves = c->n_slots >= 8 ? 4 : (c->n_slots >= 2 ? 2 : 1);
+    const int half = c->n_slots / nhalves;
     HIPCHK(c, hipMemcpyAsync(c->stage_bins, bins, n_bits * sizeof(tfft_bin), hipMemcpyHostToDevice, c->stream));
     int chunk = 0;
     for (int i0 = 0; i0 < n_images; i0 += half, chunk++) {
