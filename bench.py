@@ -222,6 +222,26 @@ def main():
                        "note": "SURVEY.md 8(d) byte model (full complex64 planes, 2 passes/FFT) over the whole step, per GPU"},
     }
 
+    # ---- the same round trip on ONE image at a time (BASELINE configs[1] is phrased on a single image):
+    # launch/latency bound, reported beside the batched headline, never instead of it
+    single = None
+    if rank == 0 and n_img > 1:
+        def one():
+            ctx.embed_batch_dev(1, d_img.data_ptr(), W, H, d_bins.data_ptr(), d_bits.data_ptr(), n_bits, d_stego.data_ptr(),
+                                usable_ptr=None if args.no_stats else d_usable.data_ptr())
+            ctx.extract_batch_dev(1, d_stego.data_ptr(), W, H, d_bins.data_ptr(), n_bits, d_raw.data_ptr())
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            one()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / 20
+        single = {"value": round(W * H / dt1 / 1e6, 1), "unit": "MPixels/s", "ms_per_image": round(dt1 * 1e3, 4),
+                  "note": "one image per call (24 kernel launches), same context"}
+    out["single_image"] = single
+
     if rank == 0:
         # ---- per-kernel timing with HIP events on the stream the kernels run on (tfft_profile_stage):
         # each stage is ONE batched launch over the chunk of `slots` images, exactly as in the timed step
