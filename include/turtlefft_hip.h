@@ -146,6 +146,16 @@ int tfft_embed_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w
 int tfft_extract_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
                            const void* bins_dev, uint64_t n_bits, double alpha, void* bits_out_dev);
 
+/* Stream framing on the device.  expand: for each of n_images, the 38-byte header and
+ * payload_len bytes of (ciphertext || tag) become the one-byte-per-bit stream Rep-3(header) || Rep-7(payload),
+ * MSB first -- bits_from_bytes + rep3/rep7_encode (S:455-467, S:494-500, S:986-995).  majority: the inverse,
+ * rep3/rep7_decode + bytes_from_bits (S:447-454, S:468-474, S:501-508) on 912 + 56*payload_len raw bits per
+ * image.  header/payload arrays are packed per image (38 and payload_len bytes apart). */
+int tfft_frame_expand_dev(tfft_ctx* ctx, int n_images, const void* header_dev, const void* payload_dev, uint64_t payload_len,
+                          void* bits_out_dev);
+int tfft_frame_majority_dev(tfft_ctx* ctx, int n_images, const void* bits_dev, uint64_t payload_len, void* header_out_dev,
+                            void* payload_out_dev);
+
 /* The same two pipelines for HOST buffers (images packed back to back, one byte per bit): the slots
  * are split into two halves and three HIP streams overlap the PCIe copy-in of the next half-batch,
  * the kernels of the current one and the copy-out of the previous one.  The

@@ -48,6 +48,8 @@ SYMBOLS = {
     "tfft_download_spectrum": (_i, [_vp, _i, _vp]),
     "tfft_embed_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
     "tfft_extract_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
+    "tfft_frame_expand_dev": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "tfft_frame_majority_dev": (_i, [_vp, _i, _vp, _u64, _vp, _vp]),
     "tfft_embed_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
     "tfft_extract_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
     "tfft_host_alloc": (_vp, [C.c_size_t]),
@@ -295,6 +297,14 @@ class Context:
         n, h, w = rgb.shape[:3]
         _check(self.lib.tfft_extract_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), bits_out.shape[1], alpha,
                                            _ptr(bits_out)), "tfft_extract_batch")
+
+    def frame_expand_dev(self, n_images, header_ptr, payload_ptr, payload_len, bits_out_ptr):
+        _check(self.lib.tfft_frame_expand_dev(self.h, n_images, _ptr(header_ptr), _ptr(payload_ptr), payload_len,
+                                              _ptr(bits_out_ptr)), "tfft_frame_expand_dev")
+
+    def frame_majority_dev(self, n_images, bits_ptr, payload_len, header_out_ptr, payload_out_ptr):
+        _check(self.lib.tfft_frame_majority_dev(self.h, n_images, _ptr(bits_ptr), payload_len, _ptr(header_out_ptr),
+                                                _ptr(payload_out_ptr)), "tfft_frame_majority_dev")
 
     def timer_begin(self):
         _check(self.lib.tfft_timer_begin(self.h), "tfft_timer_begin")

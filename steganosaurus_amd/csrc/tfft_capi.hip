@@ -694,6 +694,21 @@ void* tfft_host_alloc(size_t bytes) {
 }
 void tfft_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int tfft_frame_expand_dev(tfft_ctx* c, int n_images, const void* header_dev, const void* payload_dev, uint64_t payload_len,
+                          void* bits_out_dev) {
+    if (!c || n_images < 0 || !header_dev || (payload_len && !payload_dev) || !bits_out_dev) return TFFT_E_INVALID;
+    if (n_images == 0) return TFFT_OK;
+    HIPCHK(c, launch_frame_expand((const uint8_t*)header_dev, (const uint8_t*)payload_dev, payload_len, n_images, (uint8_t*)bits_out_dev, c->stream));
+    return TFFT_OK;
+}
+int tfft_frame_majority_dev(tfft_ctx* c, int n_images, const void* bits_dev, uint64_t payload_len, void* header_out_dev,
+                            void* payload_out_dev) {
+    if (!c || n_images < 0 || !bits_dev || !header_out_dev || (payload_len && !payload_out_dev)) return TFFT_E_INVALID;
+    if (n_images == 0) return TFFT_OK;
+    HIPCHK(c, launch_frame_majority((const uint8_t*)bits_dev, payload_len, n_images, (uint8_t*)header_out_dev, (uint8_t*)payload_out_dev, c->stream));
+    return TFFT_OK;
+}
+
 int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
                        const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,
                        float* ms_per_rep, int* n_launches) {

@@ -82,6 +82,10 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, hipStream_t s);
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s);
+hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,
+                               hipStream_t s);
+hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
+                                 hipStream_t s);
 hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);
 hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s);
 

@@ -949,9 +949,62 @@ __global__ void k_lowfreq(const float2* __restrict__ spec, int PH, int PW, int r
     out[e] = hypot((double)v.x, (double)v.y);
 }
 
+// ---------------------------------------------------------------------------
+// stream framing on the device: bits_from_bytes + rep3/rep7_encode (S:455-467, S:494-500)
+// and rep3/rep7_decode + bytes_from_bits (S:447-454, S:468-474, S:501-508), MSB first, one byte per bit in
+// the stream.  Only packed bytes (38-byte header, ciphertext || tag) then cross PCIe.
+//   expand  : grid (ceil(n_bits/256), n_images);  majority: grid (ceil((38+plen)/256), n_images)
+// ---------------------------------------------------------------------------
+__global__ void k_frame_expand(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t plen,
+                               uint8_t* __restrict__ bits) {
+    const uint64_t n = 38ull * 24 + plen * 56;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t img = blockIdx.y;
+    uint64_t b; const uint8_t* src;
+    if (i < 912) { b = i / 3; src = header + img * 38; }
+    else { b = (i - 912) / 7; src = payload + img * plen; }
+    bits[img * n + i] = (uint8_t)((src[b >> 3] >> (7 - (b & 7))) & 1);
+}
+__global__ void k_frame_majority(const uint8_t* __restrict__ bits, uint64_t plen, uint8_t* __restrict__ header,
+                                 uint8_t* __restrict__ payload) {
+    const uint64_t n = 38ull * 24 + plen * 56;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 38 + plen) return;
+    const uint64_t img = blockIdx.y;
+    const uint8_t* in = bits + img * n;
+    unsigned v = 0;
+    if (j < 38) {
+        for (int q = 0; q < 8; q++) {
+            const uint8_t* p = in + (j * 8 + q) * 3;
+            v = (v << 1) | ((p[0] + p[1] + p[2]) >= 2 ? 1u : 0u);
+        }
+        header[img * 38 + j] = (uint8_t)v;
+    } else {
+        const uint64_t k = j - 38;
+        for (int q = 0; q < 8; q++) {
+            const uint8_t* p = in + 912 + (k * 8 + q) * 7;
+            v = (v << 1) | ((p[0] + p[1] + p[2] + p[3] + p[4] + p[5] + p[6]) >= 4 ? 1u : 0u);
+        }
+        payload[img * plen + k] = (uint8_t)v;
+    }
+}
+
 // ===========================================================================
 // launchers
 // ===========================================================================
+hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,
+                               hipStream_t s) {
+    const uint64_t n = 38ull * 24 + plen * 56;
+    hipLaunchKernelGGL(k_frame_expand, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, header, payload, plen, bits);
+    return hipGetLastError();
+}
+hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_majority, dim3((unsigned)((38 + plen + 255) / 256), n_images), dim3(256), 0, s, bits, plen, header, payload);
+    return hipGetLastError();
+}
+
 #define TFFT_DISPATCH_LOG(n, F)                                                                   \
     switch (n) {                                                                                  \
         case 0: F(0); break; case 1: F(1); break; case 2: F(2); break; case 3: F(3); break;       \

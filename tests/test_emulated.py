@@ -151,3 +151,30 @@ def test_host_batch_pipeline_matches_device_batch(emu, orc):
         assert np.array_equal(out, ref_out) and np.array_equal(raw, ref_raw) and np.array_equal(us, ref_us), slots
         c2.close()
     ctx.close()
+
+
+def test_frame_expand_and_majority_against_reference_frames(emu, golden_dir):
+    """Device Rep-3/Rep-7 framing == the reference's own frames (kat.json), and majority decode absorbs bit errors."""
+    import json
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    ctx = B.Context(8, 8, lib=emu)
+    for fr in kat["frames"]:
+        want = np.unpackbits(np.frombuffer(bytes.fromhex(fr["bits_packed"]), np.uint8))
+        plen = len(fr["secret"]) + 16
+        n = 912 + 56 * plen
+        want = want[:n]
+        hdr = np.packbits((want[:912].reshape(-1, 3).sum(1) >= 2).astype(np.uint8))
+        pay = np.packbits((want[912:].reshape(-1, 7).sum(1) >= 4).astype(np.uint8))
+        assert hdr.tobytes()[:4] == b"FTTG" and len(hdr) == 38 and len(pay) == plen
+        nimg = 3
+        H = np.tile(hdr, (nimg, 1)).copy(); P = np.tile(pay, (nimg, 1)).copy()
+        bits = np.zeros((nimg, n), np.uint8)
+        ctx.frame_expand_dev(nimg, H.ctypes.data, P.ctypes.data, plen, bits.ctypes.data)
+        ctx.sync()
+        assert all(np.array_equal(bits[i], want) for i in range(nimg))
+        noisy = bits.copy(); noisy[:, ::5] ^= 1
+        H2 = np.zeros_like(H); P2 = np.zeros_like(P)
+        ctx.frame_majority_dev(nimg, noisy.ctypes.data, plen, H2.ctypes.data, P2.ctypes.data)
+        ctx.sync()
+        assert np.array_equal(H2, H) and np.array_equal(P2, P)
+    ctx.close()

@@ -308,3 +308,32 @@ def test_host_batch_pipeline(lib, orc):
     assert np.array_equal(us.astype(np.int64), d_us.cpu().numpy())
     lib.tfft_host_free(p_in); lib.tfft_host_free(p_out)
     ctx.close()
+
+
+def test_frame_expand_and_majority_on_device(lib, golden_dir):
+    import json
+    import torch
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    dev = torch.device("cuda:0")
+    ctx = B.Context(8, 8, lib=lib)
+    for fr in kat["frames"]:
+        plen = len(fr["secret"]) + 16
+        n = 912 + 56 * plen
+        want = np.unpackbits(np.frombuffer(bytes.fromhex(fr["bits_packed"]), np.uint8))[:n]
+        hdr = np.packbits((want[:912].reshape(-1, 3).sum(1) >= 2).astype(np.uint8))
+        pay = np.packbits((want[912:].reshape(-1, 7).sum(1) >= 4).astype(np.uint8))
+        nimg = 4
+        d_h = torch.from_numpy(np.tile(hdr, (nimg, 1)).copy()).to(dev); d_p = torch.from_numpy(np.tile(pay, (nimg, 1)).copy()).to(dev)
+        d_bits = torch.zeros((nimg, n), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.frame_expand_dev(nimg, d_h.data_ptr(), d_p.data_ptr(), plen, d_bits.data_ptr())
+        ctx.sync()
+        got = d_bits.cpu().numpy()
+        assert all(np.array_equal(got[i], want) for i in range(nimg))
+        noisy = got.copy(); noisy[:, ::5] ^= 1
+        d_n = torch.from_numpy(noisy).to(dev); d_h2 = torch.zeros_like(d_h); d_p2 = torch.zeros_like(d_p)
+        torch.cuda.synchronize()
+        ctx.frame_majority_dev(nimg, d_n.data_ptr(), plen, d_h2.data_ptr(), d_p2.data_ptr())
+        ctx.sync()
+        assert torch.equal(d_h2, d_h) and torch.equal(d_p2, d_p)
+    ctx.close()
