@@ -131,6 +131,38 @@ def check_median_paths(lib, orc, sizes):
     ctx.close()
 
 
+def check_context_reuse(lib, orc, max_wh, sizes):
+    """One context, many geometries in sequence (plans switch between direct / two-step / fused columns, big
+    then small images reuse the same pools): every result equals the one from a fresh context."""
+    ctx = B.Context(max_wh[0], max_wh[1], slots=2, lib=lib)
+    rng = np.random.default_rng(9)
+    for (w, h) in sizes:
+        img = cover_rgb(w, h, 5)
+        ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+        n = 120
+        try:
+            bins = B.Walk(orc.subkeys(PK)[0], ph, pw, lib=lib).next(n)
+        except B.TfftError:
+            bins = None                      # too small for 120 positions: transform-only check
+        bits = rng.integers(0, 2, n).astype(np.uint8)
+        res = []
+        for c in (ctx, B.Context(w, h, lib=lib)):
+            slot = 1 if c is ctx else 0
+            c.forward_rgb8(img, slot=slot)
+            spec = c.download_spectrum(pw, ph, slot=slot)
+            med = c.medians(slot=slot)
+            if bins is not None:
+                c.embed_bins(bins, bits, slot=slot)
+            out = c.inverse_rgb8(w, h, slot=slot)
+            res.append((spec, med, out))
+            if c is not ctx:
+                c.close()
+        assert np.array_equal(res[0][0], res[1][0]), (w, h)
+        assert np.array_equal(res[0][1], res[1][1]), (w, h)
+        assert np.array_equal(res[0][2], res[1][2]), (w, h)
+    ctx.close()
+
+
 def check_identity_roundtrip(lib, sizes):
     """forward -> inverse with no embedding returns the cover exactly (integers survive fp32)."""
     for (w, h) in sizes:

@@ -178,3 +178,7 @@ def test_frame_expand_and_majority_against_reference_frames(emu, golden_dir):
         ctx.sync()
         assert np.array_equal(H2, H) and np.array_equal(P2, P)
     ctx.close()
+
+
+def test_context_reuse_across_geometries(emu, orc):
+    PC.check_context_reuse(emu, orc, (2048, 160), [(2048, 130), (64, 64), (1500, 140), (40, 24), (700, 160), (2047, 129), (9, 5)])

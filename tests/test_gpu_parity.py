@@ -337,3 +337,8 @@ def test_frame_expand_and_majority_on_device(lib, golden_dir):
         ctx.sync()
         assert torch.equal(d_h2, d_h) and torch.equal(d_p2, d_p)
     ctx.close()
+
+
+def test_context_reuse_across_geometries(lib, orc):
+    PC.check_context_reuse(lib, orc, (3840, 2160), [(3840, 2160), (640, 360), (1920, 1080), (64, 64), (512, 512), (2048, 1024),
+                                                    (1000, 3), (1920, 1080), (100, 2000)])
