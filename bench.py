@@ -37,6 +37,7 @@ WORKLOADS = {
     "8192_single": (8192, 8192, 131072, 1, "configs[4]: 8192x8192 RGB, 128 KB payload"),
     "512_single": (512, 512, 1024, 1, "configs[0]: 512x512 RGB, 1 KB secret"),
     "1000p_batch": (1920, 1000, 4096, 32, "experiment: 1920x1000 pads to 2048x1024 (column length 1024)"),
+    "4kx500_batch": (3840, 500, 256, 32, "experiment: 3840x500 pads to 4096x512 (direct column length 512)"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C64 = 8                      # bytes per complex64 bin
@@ -247,7 +248,7 @@ def main():
         # each stage is ONE batched launch over the chunk of `slots` images, exactly as in the timed step
         ctx.forward_rgb8_dev(d_img.data_ptr(), W, H)
         ctx.sync()
-        two_step = PH > (1 << int(os.environ.get("TFFT_COLS_DIRECT_MAX_LOG", "9")))
+        two_step = PH > (1 << int(os.environ.get("TFFT_COLS_DIRECT_MAX_LOG", "8")))
         stages = {}
 
         def prof(sid, reps):

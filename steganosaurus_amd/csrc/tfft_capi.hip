@@ -60,7 +60,7 @@ struct tfft_ctx {
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
     hipEvent_t ev_in[4] = {}, ev_comp[4] = {}, ev_out[4] = {};
     uint8_t* out_pool = nullptr;
-    int cols_direct_max_log = 9;          // PH <= 512: one column pass; taller: two-step N1 x N2
+    int cols_direct_max_log = 8;          // PH <= 256: one column pass; taller: two-step N1 x N2 (a direct 512 pass reaches 1.8-3.4 TB/s, the two steps 5-6)
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
     int rows_per_block = 8;

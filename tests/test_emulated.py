@@ -29,7 +29,7 @@ def test_forward_small(emu, orc):
 
 
 def test_forward_two_step_columns(emu, orc):
-    # PH = 1024 > 512 takes the two-step (N1 x N2) column path
+    # PH = 1024 > 256 takes the two-step (N1 x N2) column path
     PC.check_forward_against_oracle(emu, orc, [(8, 1024), (20, 600)], centers=(0,))
 
 
