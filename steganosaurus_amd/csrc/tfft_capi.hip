@@ -63,7 +63,6 @@ struct tfft_ctx {
     int cols_direct_max_log = 8;          // PH <= 256: one column pass; taller: two-step N1 x N2 (a direct 512 pass reaches 1.8-3.4 TB/s, the two steps 5-6)
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
-    int rows_per_block = 8;
     int median_force_fallback = 0;
     int fuse = 1;
 
@@ -153,7 +152,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     cp.tiles_per_block = c->cols_tiles_per_block;
     switch (stage) {
         case ROWS_FWD: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->rows_per_block, n};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride};
             if (pl.fused_fwd) HIPCHK(c, launch_rowcol_fwd(rgb_in, tmp, tw_w, tw_h, rp, n, st));   // rows + column step A
             else HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
             return TFFT_OK;
@@ -190,7 +189,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->rows_per_block, n};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride};
             if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
             else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
@@ -320,7 +319,6 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
-    if (const char* e = getenv("TFFT_ROWS_PER_BLOCK")) c->rows_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }

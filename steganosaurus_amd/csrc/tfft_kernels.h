@@ -13,8 +13,6 @@ struct RowParams {
     int center;      // (-1)^(x+y) pre/post multiply (apply_center)
     float scale;     // inverse only: 1/((PW/2)*PH)
     size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
-    int rows_per_block;  // consecutive rows walked by one workgroup
-    int n_images;        // images in this launch (extent of the u8 buffer)
 };
 
 struct ColParams {
