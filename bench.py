@@ -324,6 +324,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     if world > 1:
+        dist.barrier()          # rank 0 did its extra per-kernel profiling while the others waited here
         dist.destroy_process_group()
 
 
