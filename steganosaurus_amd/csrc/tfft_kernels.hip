@@ -181,6 +181,11 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     LayRows lay{LayRows::padded(M)};
     const bool live = y < P.H;          // wave uniform: a row is exactly one wave
 
+    // pass twiddles exp(+2 pi i j/M), j < M, staged once per workgroup behind the row slabs: the radix
+    // passes then read them with LDS latency instead of L2 latency (8 KB; two workgroups still fit a CU)
+    float2* ltw = lds + (size_t)N1 * lay.pitch;
+    for (int j = n1 * T + t; j < M; j += T * N1) ltw[j] = tw[2 * j];
+
     constexpr int NSPLIT = (M / 2) / T + 1;
     float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW): lane-only indices, fetched before the staging
     if (live) {
@@ -208,14 +213,16 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
                 ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
             }
         }
-        WaveSync::sync();
+    }
+    __syncthreads();                    // the twiddle table and every live row are staged
+    if (live) {
         float2 u[E];
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
         WaveSync::sync();
-        // pass twiddles are read at the point of use: prefetching them (54 more VGPRs) leaves room for one
-        // workgroup per CU instead of two and measured 0.87 ms against 0.66 ms per 32-image launch
-        fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, tw, 2);
+        // pass twiddles are read at the point of use from the LDS copy: prefetching them into registers
+        // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
+        fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];
         WaveSync::sync();
@@ -1051,7 +1058,7 @@ hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw,
 hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
                              int n_images, hipStream_t s) {
     constexpr int LOGN1 = 3;
-    const size_t lds = (size_t)(1 << LOGN1) * LayRows::padded(1024) * sizeof(float2);
+    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024) * sizeof(float2);    // row slabs + twiddle table
     auto k = k_rowcol_fwd<LOGN1>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
