@@ -187,6 +187,29 @@ int tfft_walk_destroy(tfft_walk* w);
  * order; two bytes are consumed per bin even when max_jitter == 0 (S:719). */
 int tfft_walk_jitter(const uint8_t keys_rgb[96], const tfft_bin* bins, uint64_t n, double max_jitter, float* out);
 
+/* ------------------------------------------------------- bin visiting order
+ * (new; no counterpart in the reference, whose loop S:1074-1097 visits the
+ * bins in walk order because it materialises them one at a time.)  The walk
+ * is a pseudo-random tour, so in walk order every bin is its own DRAM row
+ * activation.  The result of embed/read does not depend on the order in which
+ * distinct bins are visited (the walk never yields a bin or its mirror twice,
+ * S:793-809), so the kernels may visit them in address order:
+ *   tfft_bins_sort   (host) sorts `bins` in place by (plane, y, x) and writes
+ *                    bit_index[i] = the position bins[i] had in the walk, i.e.
+ *                    the stream bit it carries.  Compute jitter (tfft_walk_jitter)
+ *                    BEFORE sorting: jitter stays indexed by stream bit.
+ *   tfft_set_bit_index  hands that index (host array; copied to the device) to
+ *                    the context.  From then on every embed/read/batch call on
+ *                    it reads bits[bit_index[i]] / jitter[bit_index[i]] and
+ *                    writes bits_out[bit_index[i]] for bins[i]; `bits`,
+ *                    `jitter` and `bits_out` keep their stream order, so the
+ *                    caller-visible results are identical to the unsorted call.
+ *                    The index must be a permutation of 0..n-1 (else
+ *                    TFFT_E_INVALID) and calls with a different n fail with
+ *                    TFFT_E_STATE until it is cleared with (ctx, NULL, 0). */
+int tfft_bins_sort(tfft_bin* bins, uint32_t* bit_index, uint64_t n);
+int tfft_set_bit_index(tfft_ctx* ctx, const uint32_t* bit_index, uint64_t n);
+
 /* ------------------------------------------------------------ measurement
  * Device-side timing of whatever was enqueued between the two calls on the
  * context's stream (hipEvent pair on that stream). */

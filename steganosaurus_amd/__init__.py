@@ -6,6 +6,6 @@ Only what the path needs lives here:
   binding.py            ctypes plumbing for tests / bench (no CPU fallback)
   synth.py              synthetic covers and secrets used by tests, bench and golden generation
 """
-from .binding import BIN_DTYPE, Context, TfftError, Walk, load, make_bins, bins_to_triples, walk_jitter  # noqa: F401
+from .binding import BIN_DTYPE, Context, TfftError, Walk, load, make_bins, bins_to_triples, walk_jitter, bins_sort  # noqa: F401
 
-__all__ = ["BIN_DTYPE", "Context", "TfftError", "Walk", "load", "make_bins", "bins_to_triples", "walk_jitter"]
+__all__ = ["BIN_DTYPE", "Context", "TfftError", "Walk", "load", "make_bins", "bins_to_triples", "walk_jitter", "bins_sort"]

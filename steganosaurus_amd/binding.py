@@ -60,6 +60,8 @@ SYMBOLS = {
     "tfft_walk_ks_blocks": (C.c_uint32, [_vp]),
     "tfft_walk_destroy": (_i, [_vp]),
     "tfft_walk_jitter": (_i, [C.c_char_p, _vp, _u64, _d, _vp]),
+    "tfft_bins_sort": (_i, [_vp, _vp, _u64]),
+    "tfft_set_bit_index": (_i, [_vp, _vp, _u64]),
     "tfft_profile_stage": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _d, C.POINTER(C.c_float), _pi]),
     "tfft_timer_begin": (_i, [_vp]),
     "tfft_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
@@ -160,6 +162,15 @@ def walk_jitter(keys_rgb: bytes, bins, max_jitter, lib=None):
     return out
 
 
+def bins_sort(bins, lib=None):
+    """Address-ordered copy of a bin list and bit_index (bit_index[i] = walk position of sorted bin i)."""
+    lib = lib or load()
+    out = np.ascontiguousarray(bins, BIN_DTYPE).copy()
+    idx = np.zeros(len(out), np.uint32)
+    _check(lib.tfft_bins_sort(_ptr(out), _ptr(idx), len(out)), "tfft_bins_sort")
+    return out, idx
+
+
 class Context:
     """One tfft_ctx: `slots` resident images of up to max_w x max_h on HIP device `device`."""
 
@@ -185,6 +196,14 @@ class Context:
 
     def sync(self):
         _check(self.lib.tfft_sync(self.h), "tfft_sync")
+
+    def set_bit_index(self, bit_index=None):
+        """bins[i] of later embed/read/batch calls carries stream bit bit_index[i]; None clears."""
+        if bit_index is None:
+            _check(self.lib.tfft_set_bit_index(self.h, None, 0), "tfft_set_bit_index")
+            return
+        idx = np.ascontiguousarray(bit_index, np.uint32)
+        _check(self.lib.tfft_set_bit_index(self.h, _ptr(idx), len(idx)), "tfft_set_bit_index")
 
     def device_bytes(self):
         return self.lib.tfft_device_bytes(self.h)

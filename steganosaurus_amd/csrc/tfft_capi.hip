@@ -15,6 +15,8 @@
 #include "tfft_kernels.h"
 
 extern "C" void tfft_internal_radius_bounds(double lo, double hi, uint64_t* s_lo, uint64_t* s_hi, int* empty);
+// host view of the capacity kernel's threshold transform (tests/test_host.py checks it against the reference's compare)
+extern "C" float tfft_internal_mag2_threshold(double thr) { return tfft::mag2_threshold(thr); }
 
 namespace {
 
@@ -54,6 +56,8 @@ struct tfft_ctx {
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS]
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
+    uint32_t* bit_index = nullptr;        // tfft_set_bit_index: bins[i] carries stream bit bit_index[i]
+    uint64_t bit_index_n = 0;
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
@@ -228,8 +232,11 @@ EmbedParams embed_params(const tfft_ctx* c, const Slot& s, uint64_t n, double al
     p.alpha = alpha;
     for (int i = 0; i < 3; i++) p.med[i] = med ? med[i] : 0.0;
     p.img_stride = c->slot_stride;
+    p.bit_index = c->bit_index;            // callers check index_ok(c, n) first
     return p;
 }
+// a bit index, once set, must describe exactly the bin list it is used with
+static inline bool index_ok(const tfft_ctx* c, uint64_t n) { return !c->bit_index || c->bit_index_n == n; }
 
 CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax) {
     CapParams p{};
@@ -351,7 +358,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
     (void)hipFree(c->out_pool);
@@ -456,11 +463,39 @@ int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
     return TFFT_OK;
 }
 
+int tfft_set_bit_index(tfft_ctx* c, const uint32_t* bit_index, uint64_t n) {
+    if (!c) return TFFT_E_INVALID;
+    if (!bit_index || n == 0) {            // back to "bins[i] carries bit i"
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->bit_index);
+        c->bit_index = nullptr; c->bit_index_n = 0;
+        return TFFT_OK;
+    }
+    if (n > 0xFFFFFFFFull) return TFFT_E_TOO_LARGE;
+    // the kernels index bits/jitter/bits_out with these values: they must be a permutation of 0..n-1
+    std::vector<uint64_t> seen((n + 63) / 64, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t j = bit_index[i];
+        if (j >= n || (seen[j >> 6] >> (j & 63)) & 1) return TFFT_E_INVALID;
+        seen[j >> 6] |= 1ull << (j & 63);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->bit_index_n != n || !c->bit_index) {
+        (void)hipFree(c->bit_index);
+        c->bit_index = nullptr; c->bit_index_n = 0;
+        int rc = dev_alloc(c, (void**)&c->bit_index, n * sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipMemcpy(c->bit_index, bit_index, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->bit_index_n = n;
+    return TFFT_OK;
+}
+
 int tfft_embed_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* bits, const void* jitter, uint64_t n,
                         double alpha, int adaptive, const double med[3]) {
     if (!slot_ok(c, slot) || (n && (!bins || !bits)) || (adaptive && !med)) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
-    if (!s.has_spec) return TFFT_E_STATE;
+    if (!s.has_spec || !index_ok(c, n)) return TFFT_E_STATE;
     EmbedParams p = embed_params(c, s, n, alpha, adaptive, med, jitter != nullptr);
     HIPCHK(c, launch_embed(c->spec(slot), (const tfft_bin*)bins, (const uint8_t*)bits, (const float*)jitter, p, 1, c->err, c->stream));
     return TFFT_OK;
@@ -485,7 +520,7 @@ int tfft_read_bins_dev(tfft_ctx* c, int slot, const void* bins, const void* jitt
                        int adaptive, const double med[3], void* bits_out) {
     if (!slot_ok(c, slot) || (n && (!bins || !bits_out)) || (adaptive && !med)) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
-    if (!s.has_spec) return TFFT_E_STATE;
+    if (!s.has_spec || !index_ok(c, n)) return TFFT_E_STATE;
     EmbedParams p = embed_params(c, s, n, alpha, adaptive, med, jitter != nullptr);
     HIPCHK(c, launch_read(c->spec(slot), (const tfft_bin*)bins, (const float*)jitter, p, 1, (uint8_t*)bits_out, c->err, c->stream));
     return TFFT_OK;
@@ -551,6 +586,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
                        unsigned long long* usable, uint8_t* rgb_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
+    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
     if (rc) return rc;
     if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip
@@ -567,6 +603,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
 static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, uint64_t n_bits,
                          double alpha, uint8_t* bits_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
+    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
     if (rc) return rc;
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
@@ -729,11 +766,13 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         int rc = TFFT_OK;
         switch (stage) {
             case EMBED: {
+                if (!index_ok(c, n_bits)) return TFFT_E_STATE;
                 EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
                 HIPCHK(c, launch_embed(c->spec(0), (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev, nullptr, ep, n_images, c->err, c->stream));
                 break;
             }
             case READ: {
+                if (!index_ok(c, n_bits)) return TFFT_E_STATE;
                 EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
                 HIPCHK(c, launch_read(c->spec(0), (const tfft_bin*)bins_dev, nullptr, ep, n_images, (uint8_t*)bits_out_dev, c->err, c->stream));
                 break;

@@ -1,6 +1,8 @@
 // tfft_kernels.h -- parameter blocks and launchers shared by tfft_kernels.hip and tfft_capi.hip
 #pragma once
 #include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/turtlefft_hip.h"
@@ -38,6 +40,7 @@ struct EmbedParams {
     double alpha;
     double med[3];
     size_t img_stride;     // float2 elements between images (grid.y = image)
+    const uint32_t* bit_index;   // bins[i] carries stream bit bit_index[i] (nullptr: bit i); tfft_set_bit_index
 };
 
 struct CapParams {
@@ -49,6 +52,22 @@ struct CapParams {
     double thr[3];                  // used when med_dev == nullptr (tfft_capacity)
     size_t img_stride;
 };
+
+// Smallest float m2 with (double)sqrtf(m2) >= thr, i.e. the reference's test !(|F| < thr) (S:1004) moved
+// onto the argument of mag_of's square root: sqrtf is correctly rounded and monotone, so
+// !((double)sqrtf(m2) < thr)  <=>  !(m2 < T2).  One scalar search per thread (wave uniform) replaces a
+// correctly rounded square root and a double compare per bin.
+__host__ __device__ inline float mag2_threshold(double thr) {
+    if (!(thr > 0.0)) return -INFINITY;                 // thr <= 0 or NaN: nothing is ever "< thr"
+    float tf = (float)thr;                              // tf = smallest float >= thr
+    if ((double)tf < thr) tf = nextafterf(tf, INFINITY);
+    if (!(tf < INFINITY)) return INFINITY;
+    float c = tf * tf;
+    if (!(c < INFINITY)) c = FLT_MAX;
+    for (int i = 0; i < 8 && !(sqrtf(c) < tf); i++) c = nextafterf(c, -INFINITY);   // now sqrtf(c) < tf (or c ran to 0)
+    for (int i = 0; i < 16 && sqrtf(c) < tf; i++) c = nextafterf(c, INFINITY);      // first value that passes
+    return c;
+}
 
 #define TFFT_STAT_MAX_BLOCKS 512
 

@@ -16,6 +16,8 @@
 // Reference lines (steganosaurus/src/steganosaur.cpp) replaced by each kernel
 // are cited as S:<line>.
 #include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -549,6 +551,7 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     spec += (size_t)img * P.img_stride;
     bits += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
+    const uint64_t j = P.bit_index ? (uint64_t)P.bit_index[i] : i;      // the stream bit this bin carries
     const int x = bn.x, y = bn.y, p = bn.plane;
     if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
         atomicOr(err, 1);     // outside the grid or on an excluded axis (S:698-700): never produced by the walk
@@ -557,14 +560,14 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     const BinRef r = locate(p, y, x, P.PH, P.PW);
     const float2 v = spec[r.idx];
     const float mag = fmaxf(1e-12f, mag_of(v));
-    const int bit = bits[i];
+    const int bit = bits[j];
     float2 nv;
     if (!P.generic) {
         nv = make_float2(mag * P.cos_a, bit ? mag * P.sin_a : -mag * P.sin_a);
     } else {
         double alpha = P.alpha;
         if (P.adaptive) alpha *= fmin(2.0, fmax(0.5, (double)mag / fmax(1e-12, P.med[p])));   // S:704-710
-        const double theta = (bit ? alpha : -alpha) + (jitter ? (double)jitter[i] : 0.0);
+        const double theta = (bit ? alpha : -alpha) + (jitter ? (double)jitter[j] : 0.0);
         nv = make_float2((float)((double)mag * cos(theta)), (float)((double)mag * sin(theta)));
     }
     spec[r.idx] = r.conj ? cconj(nv) : nv;    // the Hermitian mirror is implicit in the half spectrum
@@ -580,10 +583,11 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
     spec += (size_t)img * P.img_stride;
     bits_out += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
+    const uint64_t j = P.bit_index ? (uint64_t)P.bit_index[i] : i;
     const int x = bn.x, y = bn.y, p = bn.plane;
     if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
         atomicOr(err, 1);
-        bits_out[i] = 0;
+        bits_out[j] = 0;
         return;
     }
     const BinRef r = locate(p, y, x, P.PH, P.PW);
@@ -600,12 +604,12 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
             const double mag = fmax(1e-12, (double)mag_of(v));
             alpha *= fmin(2.0, fmax(0.5, mag / fmax(1e-12, P.med[p])));
         }
-        const double j = jitter ? (double)jitter[i] : 0.0;
-        double dp = fmod(th - (j + alpha) + PI, 2 * PI); if (dp < 0) dp += 2 * PI; dp = fabs(dp - PI);
-        double dn = fmod(th - (j - alpha) + PI, 2 * PI); if (dn < 0) dn += 2 * PI; dn = fabs(dn - PI);
+        const double jt = jitter ? (double)jitter[j] : 0.0;
+        double dp = fmod(th - (jt + alpha) + PI, 2 * PI); if (dp < 0) dp += 2 * PI; dp = fabs(dp - PI);
+        double dn = fmod(th - (jt - alpha) + PI, 2 * PI); if (dn < 0) dn += 2 * PI; dn = fabs(dn - PI);
         bit = (dp <= dn) ? 1 : 0;
     }
-    bits_out[i] = (uint8_t)bit;
+    bits_out[j] = (uint8_t)bit;
 }
 
 // ---------------------------------------------------------------------------
@@ -713,7 +717,30 @@ __global__ void k_select_guess(SelectState* __restrict__ st) {
 // One pass over the whole spectrum: weight of everything below the bracket (registers -> one atomic per
 // block) and compaction of the bracket's members.  Each WAVE stages its candidates in a private LDS
 // buffer and flushes it with one global atomic when it is half full: no workgroup barrier in the loop.
-__global__ void k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
+// A wave walks whole rows in segments of 1024 columns (8 x 16-byte loads per lane) and issues the loads
+// of the NEXT segment before it classifies the current one, so ~16 KB per wave are in flight: with one
+// segment of 256 columns per dependent step the pass ran at 3 TB/s, bound by load latency.
+// rank of this lane among the set bits of a wave mask (v_mbcnt_lo/hi)
+__device__ __forceinline__ unsigned wave_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+struct BracketSeg {
+    float4 v[8];                        // columns x0 + 2*(q*64 + lane) and the one after it
+    float2 partner;                     // lane 0 of segment 0: row PH-y of the packed column 0
+};
+__device__ __forceinline__ void bracket_load(BracketSeg& r, const float2* __restrict__ pl, int PH, int M, int y, int x0, int lane) {
+    const float2* row = pl + (size_t)y * M;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int x = x0 + 2 * (q * 64 + lane);
+        if (x + 1 < M) r.v[q] = *reinterpret_cast<const float4*>(row + x);
+        else if (x < M) { const float2 a = row[x]; r.v[q] = make_float4(a.x, a.y, 0.f, 0.f); }   // M == 1
+        else r.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    r.partner = make_float2(0.f, 0.f);
+    if (x0 == 0 && lane == 0) r.partner = pl[(size_t)((PH - y) & (PH - 1)) * M];
+}
+__global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
                                   SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
     unsigned* wbuf = hist + 1024;                                 // 4 waves x 512 staged candidates
@@ -727,46 +754,71 @@ __global__ void k_collect_bracket(const float2* __restrict__ spec, int PH, int M
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
     if (lane == 0) cnt[0] = 0;
     __syncthreads();
-    unsigned long long below = 0;
-    // every wave walks whole rows in steps of 256 columns (4 per lane); the trip counts are wave uniform
-    for (int y = blockIdx.x * 4 + wave; y < PH; y += gridDim.x * 4) {
-        for (int x0 = 0; x0 < M; x0 += 256) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int x = x0 + q * 64 + lane;
-                if (x < M)
-                    for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
-                        const unsigned bk = b >> 19;
-                        if (bk < lo) below += w;
-                        else if (bk <= hi) {
-                            const unsigned rel = b - base_bits;                  // < 3 * 2^19
-                            buf[atomicAdd(&cnt[0], 1u)] = rel | (w == 2u ? 0x80000000u : 0u);
-                            atomicAdd(&hist[rel >> 11], w);
-                        }
-                    });
+    // Per element: one compare-and-add for the weight below the bracket and one ballot for membership.
+    // The staged count lives in a wave-uniform register (ballot + popcount), slots come from mbcnt: no
+    // returning LDS atomic and no divergent branch on the common path -- the first version spent ~150
+    // instructions per element on exec-masked branches and ran at 3 TB/s, instruction bound.
+    unsigned below32 = 0;               // per lane < 2^32: a lane sees at most PH*PW/64 weights
+    unsigned nstaged = 0;               // wave uniform
+    const unsigned span = hi - lo;
+    auto classify = [&](bool valid, unsigned b, unsigned w) {
+        const unsigned bk = b >> 19;
+        below32 += (valid && bk < lo) ? w : 0u;
+        const bool c = valid && (bk - lo) <= span;
+        const unsigned long long m = __ballot(c);
+        if (m) {                        // wave uniform
+            if (c) {
+                const unsigned rel = b - base_bits;              // < 3 * 2^19
+                buf[nstaged + wave_rank(m)] = rel | (w == 2u ? 0x80000000u : 0u);
+                atomicAdd(&hist[rel >> 11], w);
             }
-            WaveSync::sync();
-            const unsigned n = cnt[0];
-            if (n > 250) {                                                       // at most 4*65 more fit per step
-                if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, n);
+            nstaged += (unsigned)__popcll(m);
+        }
+    };
+    // the trip counts are wave uniform: (y, x0) advance identically in every lane
+    const int ystep = gridDim.x * 4;
+    int y = blockIdx.x * 4 + wave, x0 = 0;
+    bool have = y < PH;
+    BracketSeg cur;
+    if (have) bracket_load(cur, pl, PH, M, y, x0, lane);
+    while (have) {
+        int ny = y, nx0 = x0 + 1024;
+        if (nx0 >= M) { nx0 = 0; ny = y + ystep; }
+        const bool nhave = ny < PH;
+        BracketSeg nxt;
+        if (nhave) bracket_load(nxt, pl, PH, M, ny, nx0, lane);
+        if (x0 == 0) {                  // packed column 0 (lane 0): F[y][0] and F[y][M], once each (unpack_col0)
+            const float2 a = make_float2(cur.v[0].x, cur.v[0].y), b2 = cur.partner;
+            const float2 f0 = make_float2(0.5f * (a.x + b2.x), 0.5f * (a.y - b2.y));
+            const float2 fm = make_float2(0.5f * (a.y + b2.y), -0.5f * (a.x - b2.x));
+            classify(lane == 0, __float_as_uint(mag2_of(f0)), 1u);
+            classify(lane == 0, __float_as_uint(mag2_of(fm)), 1u);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int x = x0 + 2 * (q * 64 + lane);
+            classify(x != 0 && x < M, __float_as_uint(mag2_of(make_float2(cur.v[q].x, cur.v[q].y))), 2u);
+            classify(x + 1 < M, __float_as_uint(mag2_of(make_float2(cur.v[q].z, cur.v[q].w))), 2u);
+            if ((q & 1) && nstaged > 250) {     // at most 4 * 64 + 2 more before the next check: 508 <= 512
+                WaveSync::sync();
+                if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, nstaged);
                 WaveSync::sync();
                 const unsigned gbase = cnt[1];
-                for (unsigned i = lane; i < n; i += 64) out[gbase + i] = buf[i];
+                for (unsigned i = lane; i < nstaged; i += 64) out[gbase + i] = buf[i];
                 WaveSync::sync();
-                if (lane == 0) cnt[0] = 0;
+                nstaged = 0;
             }
-            WaveSync::sync();
         }
+        cur = nxt; y = ny; x0 = nx0; have = nhave;
     }
-    {   // final flush of this wave
-        const unsigned n = cnt[0];
-        if (n) {
-            if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, n);
-            WaveSync::sync();
-            const unsigned gbase = cnt[1];
-            for (unsigned i = lane; i < n; i += 64) out[gbase + i] = buf[i];
-        }
+    if (nstaged) {   // final flush of this wave
+        WaveSync::sync();
+        if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, nstaged);
+        WaveSync::sync();
+        const unsigned gbase = cnt[1];
+        for (unsigned i = lane; i < nstaged; i += 64) out[gbase + i] = buf[i];
     }
+    unsigned long long below = below32;
     if (below) atomicAdd(&s->below, below);
     __syncthreads();
     for (int i = threadIdx.x; i < 1024; i += blockDim.x)
@@ -900,38 +952,54 @@ __global__ void k_collect(const float2* __restrict__ spec, int PH, int M, size_t
 // walks rows of the box and writes ONE partial count (no global atomics).
 //   grid (NB, 3, n_images)  block 256   partial[(img*3+plane)*NB + block]
 // ---------------------------------------------------------------------------
-__global__ void k_capacity(const float2* __restrict__ spec, CapParams P, const float* __restrict__ med_dev,
+// WIDE: grids beyond 32768 need 64-bit y*y+x*x
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_capacity(const float2* __restrict__ spec, CapParams P, const float* __restrict__ med_dev,
                            unsigned* __restrict__ partial) {
     unsigned* blk = reinterpret_cast<unsigned*>(tfft_smem);
     if (threadIdx.x == 0) blk[0] = 0;
     __syncthreads();
     const int plane = blockIdx.y, img = blockIdx.z;
     const double thr = med_dev ? P.magmin * (double)med_dev[img * 3 + plane] : P.thr[plane];
-    const float2* pl = spec + (size_t)img * P.img_stride + (size_t)plane * P.PH * (P.PWi >> 1);
+    const float t2 = mag2_threshold(thr);
+    const int M = P.PWi >> 1;
+    const float2* pl = spec + (size_t)img * P.img_stride + (size_t)plane * P.PH * M;
+    typedef typename std::conditional<WIDE, unsigned long long, unsigned>::type R;
+    const R s_lo = (R)P.s_lo, s_hi = (R)P.s_hi;
     unsigned mine = 0;
     for (int y = blockIdx.x; y < P.bh; y += gridDim.x) {
         if (y == 0 || 2 * y == P.PH) continue;
-        const unsigned long long yy = (unsigned long long)y * y;
-        for (int x = threadIdx.x; x < P.bw; x += blockDim.x) {
-            const unsigned long long s = yy + (unsigned long long)x * x;
-            if (x == 0 || 2 * x == P.PW || s < P.s_lo || s > P.s_hi) continue;
-            const float2 v = full_bin(pl, y, x, P.PH, P.PWi);
-            if (!((double)mag_of(v) < thr)) mine++;
+        const R yy = (R)y * (R)y;
+        const float2* row = pl + (size_t)y * M;                                  // bins x < M
+        const float2* mrow = pl + (size_t)((P.PH - y) & (P.PH - 1)) * M;         // bins x > M: conj of (PH-y, PW-x), same magnitude
+        // four independent loads per thread in flight
+        for (int x0 = threadIdx.x; x0 < P.bw; x0 += 4 * blockDim.x) {
+            float2 v[4]; bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = x0 + u * (int)blockDim.x;
+                const R s = yy + (R)x * (R)x;
+                in[u] = x < P.bw && x != 0 && 2 * x != P.PW && s >= s_lo && s <= s_hi;
+                v[u] = in[u] ? (x < M ? row[x] : mrow[P.PW - x]) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (in[u] && !(mag2_of(v[u]) < t2)) mine++;
         }
     }
     if (mine) atomicAdd(&blk[0], mine);
     __syncthreads();
     if (threadIdx.x == 0) partial[((size_t)img * 3 + plane) * gridDim.x + blockIdx.x] = blk[0];
 }
-// usable[img] = sum_p floor(c_p/2): one thread block per image sums the partial counts
+// usable[img] = sum_p floor(c_p/2): one block of three waves per image, wave p sums the partials of plane p
 __global__ void k_capacity_final(const unsigned* __restrict__ partial, int nb, unsigned long long* __restrict__ usable) {
     unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3]
-    const int img = blockIdx.x;
-    if (threadIdx.x < 3) {
-        unsigned long long a = 0;
-        for (int i = 0; i < nb; i++) a += partial[((size_t)img * 3 + threadIdx.x) * nb + i];
-        c[threadIdx.x] = a;
-    }
+    const int img = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 3) c[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long a = 0;
+    for (int i = lane; i < nb; i += 64) a += partial[((size_t)img * 3 + p) * nb + i];
+    if (a) atomicAdd(&c[p], a);
     __syncthreads();
     if (threadIdx.x == 0) usable[img] = c[0] / 2 + c[1] / 2 + c[2] / 2;
 }
@@ -1169,9 +1237,21 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
 
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s) {
-    unsigned nb = stat_blocks(P.bh > 0 ? P.bh : 1, n_images);
-    hipLaunchKernelGGL(k_capacity, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
-    hipLaunchKernelGGL(k_capacity_final, dim3(n_images), dim3(64), 32, s, partial, (int)nb, usable);
+    // about a dozen rows of the box per block (plain stores of the partial counts, no atomics): long
+    // enough to amortise a block's start-up (threshold search, barrier), short enough that the grid still
+    // has thousands of blocks with four loads per thread in flight; a single image gets more, shorter blocks
+    const int bh = P.bh > 0 ? P.bh : 1;
+    int nbi = (bh + 11) / 12;
+    const int fill = (1024 + 3 * n_images - 1) / (3 * n_images);
+    if (nbi < fill) nbi = fill;
+    if (nbi > bh) nbi = bh;
+    if (nbi > TFFT_STAT_MAX_BLOCKS) nbi = TFFT_STAT_MAX_BLOCKS;
+    const unsigned nb = (unsigned)nbi;
+    // the exact integer radius test fits 32 bits up to 32768 x 32768 and when the host bounds do
+    const bool wide = P.PH > 32768 || P.PW > 32768 || P.s_hi > 0xFFFFFFFFull || P.s_lo > 0xFFFFFFFFull;
+    if (wide) hipLaunchKernelGGL(k_capacity<true>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
+    else hipLaunchKernelGGL(k_capacity<false>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
+    hipLaunchKernelGGL(k_capacity_final, dim3(n_images), dim3(192), 32, s, partial, (int)nb, usable);
     return hipGetLastError();
 }
 

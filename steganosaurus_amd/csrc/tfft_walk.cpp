@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -270,6 +271,30 @@ int tfft_walk_jitter(const uint8_t keys_rgb[96], const tfft_bin* bins, uint64_t 
         if (bins[i].plane > 2) return TFFT_E_BIN_RANGE;
         out[i] = ks[bins[i].plane].jitter(max_jitter);                // S:719, S:1208
     }
+    return TFFT_OK;
+}
+
+// Address order for the device kernels: stable LSD counting sort on (plane, y, x).  The walk is a
+// pseudo-random tour of the annulus, so in walk order every bin costs its own DRAM row activation;
+// visiting the same set in row-major order lets neighbouring lanes share rows and sectors.
+int tfft_bins_sort(tfft_bin* bins, uint32_t* bit_index, uint64_t n) {
+    if (n && (!bins || !bit_index)) return TFFT_E_INVALID;
+    if (n > 0xFFFFFFFFull) return TFFT_E_TOO_LARGE;
+    std::vector<tfft_bin> tb(n);
+    std::vector<uint32_t> ti(n);
+    for (uint64_t i = 0; i < n; i++) bit_index[i] = (uint32_t)i;
+    std::vector<uint64_t> cnt(65537);
+    auto pass = [&](auto key, const tfft_bin* sb, const uint32_t* si, tfft_bin* db, uint32_t* di) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (uint64_t i = 0; i < n; i++) cnt[(size_t)key(sb[i]) + 1]++;
+        for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+        for (uint64_t i = 0; i < n; i++) { const uint64_t d = cnt[key(sb[i])]++; db[d] = sb[i]; di[d] = si[i]; }
+    };
+    pass([](const tfft_bin& b) { return (unsigned)b.x; }, bins, bit_index, tb.data(), ti.data());
+    pass([](const tfft_bin& b) { return (unsigned)b.y; }, tb.data(), ti.data(), bins, bit_index);
+    pass([](const tfft_bin& b) { return (unsigned)b.plane; }, bins, bit_index, tb.data(), ti.data());
+    std::copy(tb.begin(), tb.end(), bins);
+    std::copy(ti.begin(), ti.end(), bit_index);
     return TFFT_OK;
 }
 

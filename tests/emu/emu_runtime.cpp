@@ -29,6 +29,22 @@ void trampoline() {
 void emu_syncthreads() { current->waiting = 1; swapcontext(&current->ctx, &sched_ctx); }
 void emu_wave_sync() { current->waiting = 2; swapcontext(&current->ctx, &sched_ctx); }
 
+// ballot among the 64 fibers of the wave: deposit, barrier, read, barrier, clear, barrier (the third
+// barrier keeps a fast lane's next deposit from being wiped by a slow lane's clear)
+namespace { unsigned long long ballot_acc[16]; }
+static unsigned linear_tid() { return current->tid.x + blockDim.x * (current->tid.y + blockDim.y * current->tid.z); }
+unsigned emu_lane() { return linear_tid() & 63u; }
+unsigned long long emu_ballot(int pred) {
+    const unsigned w = linear_tid() >> 6, l = linear_tid() & 63u;
+    if (pred) ballot_acc[w] |= 1ull << l;
+    emu_wave_sync();
+    const unsigned long long r = ballot_acc[w];
+    emu_wave_sync();
+    ballot_acc[w] = 0;
+    emu_wave_sync();
+    return r;
+}
+
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     if (shmem > sizeof(tfft::tfft_smem)) { fprintf(stderr, "emu: %zu bytes of LDS requested\n", shmem); abort(); }
     const size_t nt = (size_t)block.x * block.y * block.z;

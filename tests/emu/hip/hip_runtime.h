@@ -27,6 +27,8 @@
 
 struct float2 { float x, y; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -50,6 +52,15 @@ void emu_wave_sync();
 // wave-level sync points of the kernels: a barrier among the 64 fibers of the wave
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+// wave collectives (call sites must be wave uniform, as on the hardware path they are used in)
+unsigned long long emu_ballot(int pred);
+unsigned emu_lane();
+#define __ballot(p) emu_ballot((p) ? 1 : 0)
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline unsigned emu_mbcnt_lo(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (unsigned)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
+static inline unsigned emu_mbcnt_hi(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (l < 32 ? 0u : (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u))); }
+#define __builtin_amdgcn_mbcnt_lo(m, i) emu_mbcnt_lo((m), (i))
+#define __builtin_amdgcn_mbcnt_hi(m, i) emu_mbcnt_hi((m), (i))
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu_launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
 

@@ -9,6 +9,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 
 from _checkers import Params, bins_digest
 from steganosaurus_amd import binding as B
@@ -161,6 +162,49 @@ def check_context_reuse(lib, orc, max_wh, sizes):
         assert np.array_equal(res[0][1], res[1][1]), (w, h)
         assert np.array_equal(res[0][2], res[1][2]), (w, h)
     ctx.close()
+
+
+def check_bit_index(lib, orc, w, h, n, jitter=0.0):
+    """tfft_bins_sort + tfft_set_bit_index: visiting the bins in address order leaves every caller-visible
+    result identical (spectrum after embed, stego bytes, extracted bits in stream order), with and without
+    jitter; an index that is not a permutation or is used with another n is refused."""
+    img = cover_rgb(w, h, 11)
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+    keys = orc.subkeys(PK)
+    bins = B.Walk(keys[0], ph, pw, lib=lib).next(n)
+    jit = B.walk_jitter(b"".join(keys[1:4]), bins, jitter, lib=lib) if jitter else None
+    bits = np.random.default_rng(21).integers(0, 2, n).astype(np.uint8)
+    sbins, idx = B.bins_sort(bins, lib=lib)
+    key = (sbins["plane"].astype(np.int64) << 32) | (sbins["y"].astype(np.int64) << 16) | sbins["x"]
+    assert (np.diff(key) > 0).all() and np.array_equal(sbins, bins[idx]) and np.array_equal(np.sort(idx), np.arange(n))
+    res = []
+    for ordered in (False, True):
+        ctx = B.Context(w, h, lib=lib)
+        if ordered:
+            ctx.set_bit_index(idx)
+        bl = sbins if ordered else bins
+        ctx.forward_rgb8(img)
+        ctx.embed_bins(bl, bits, jitter=jit)
+        spec = ctx.download_spectrum(pw, ph)
+        stego = ctx.inverse_rgb8(w, h)
+        ctx.forward_rgb8(stego)
+        got = ctx.read_bins(bl, jitter=jit)
+        res.append((spec, stego, got))
+        if ordered:
+            with pytest.raises(B.TfftError):            # index of n entries, call with n - 1 bins
+                ctx.read_bins(bl[:-1])
+            bad = idx.copy(); bad[0] = bad[1]
+            with pytest.raises(B.TfftError):
+                ctx.set_bit_index(bad)
+            bad = idx.copy(); bad[0] = n
+            with pytest.raises(B.TfftError):
+                ctx.set_bit_index(bad)
+            ctx.set_bit_index(None)                     # cleared: plain walk order works again
+            assert np.array_equal(ctx.read_bins(bins, jitter=jit), got)
+        ctx.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    return res[0][2], bits
 
 
 def check_identity_roundtrip(lib, sizes):

@@ -182,3 +182,8 @@ def test_frame_expand_and_majority_against_reference_frames(emu, golden_dir):
 
 def test_context_reuse_across_geometries(emu, orc):
     PC.check_context_reuse(emu, orc, (2048, 160), [(2048, 130), (64, 64), (1500, 140), (40, 24), (700, 160), (2047, 129), (9, 5)])
+
+
+def test_bit_index_address_order(emu, orc):
+    PC.check_bit_index(emu, orc, 64, 48, 700)
+    PC.check_bit_index(emu, orc, 100, 64, 500, jitter=0.05)

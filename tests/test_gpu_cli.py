@@ -68,8 +68,11 @@ def test_interop_both_directions(covers):
 def test_interop_options_and_raw_key(covers):
     a = os.path.join(covers["dir"], "o.png")
     key = run(CLI, "gen-key").stdout.split("Base64: ")[1].split()[0]
-    for extra in (["--center", "1"], ["--jitter", "0.05"], ["--alpha", "0.3", "--density", "0.5", "--rmin", "0.1", "--rmax", "0.4"]):
-        r = run(CLI, "embed", "--in", covers["grad256"], "--out", a, "--secret", "opt", "--key", key, *extra)
+    # the weak-alpha case runs on the textured cover: on the smooth gradient most annulus bins are tiny, the
+    # 8-bit rounding of the stego image flips enough of them that Rep-7 decoding depends on the (random) salt
+    for cover, extra in (("grad256", ["--center", "1"]), ("grad256", ["--jitter", "0.05"]),
+                         ("lcg512", ["--alpha", "0.3", "--density", "0.5", "--rmin", "0.1", "--rmax", "0.4"])):
+        r = run(CLI, "embed", "--in", covers[cover], "--out", a, "--secret", "opt", "--key", key, *extra)
         assert r.returncode == 0, r.stderr
         r = run(REF_CLI, "extract", "--in", a, "--key", key, *extra)
         assert (r.returncode, r.stdout) == (0, "opt\n"), (extra, r.stderr)

@@ -342,3 +342,11 @@ def test_frame_expand_and_majority_on_device(lib, golden_dir):
 def test_context_reuse_across_geometries(lib, orc):
     PC.check_context_reuse(lib, orc, (3840, 2160), [(3840, 2160), (640, 360), (1920, 1080), (64, 64), (512, 512), (2048, 1024),
                                                     (1000, 3), (1920, 1080), (100, 2000)])
+
+
+@pytest.mark.gpu
+def test_bit_index_address_order(lib, orc):
+    got, bits = PC.check_bit_index(lib, orc, 512, 512, 59152)
+    assert (got != bits).mean() < 1e-3
+    PC.check_bit_index(lib, orc, 600, 400, 20000, jitter=0.05)
+    PC.check_bit_index(lib, orc, 1920, 1080, 231184)

@@ -360,3 +360,48 @@ def test_wrapped_key_from_reference_cli_unwraps(host, tmp_path):
     assert host.tfh_aead_open_turtle(derived[:32], blob[20:32], None, C.c_size_t(0), blob[32:64], C.c_size_t(32), blob[64:80], out) == 1
     assert out.raw == key
     assert host.tfh_aead_open(derived[:32], blob[20:32], None, C.c_size_t(0), blob[32:64], C.c_size_t(32), blob[64:80], out) == 0
+
+
+def test_capacity_threshold_transform_matches_reference_compare():
+    """k_capacity tests !(m2 < T2) on |F|^2 instead of the reference's !((double)|F| < thr) (S:1004):
+    T2 = tfft_internal_mag2_threshold(thr) must make the two identical for every float, in particular
+    for the neighbours of the boundary."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "steganosaurus_amd", "libturtlefft_hip.so"))
+    f = lib.tfft_internal_mag2_threshold
+    f.restype = C.c_float
+    f.argtypes = [C.c_double]
+    rng = np.random.default_rng(7)
+    thrs = np.concatenate([10.0 ** rng.uniform(-6, 9, 300), np.float32(10.0 ** rng.uniform(-3, 6, 100)).astype(np.float64),
+                           [0.0, -1.0, 1e-30, 3.0e38, 1e39, np.inf, np.nan, 1.0, 4.0, 2.0 ** -126]])
+    for thr in thrs:
+        t2 = np.float32(f(float(thr)))
+        if np.isfinite(t2) and t2 > 0:
+            around = np.float32(t2) * np.ones(129, np.float32)
+            bits = around.view(np.uint32).astype(np.int64) + np.arange(-64, 65)
+            m2 = np.clip(bits, 0, 0x7F7FFFFF).astype(np.uint32).view(np.float32)
+        else:
+            m2 = np.array([0.0, 1e-45, 1.0, 3.4e38, np.inf], np.float32)
+        m2 = np.concatenate([m2, np.float32(10.0 ** rng.uniform(-12, 18, 64))]).astype(np.float32)
+        with np.errstate(invalid="ignore"):
+            ref = ~(np.sqrt(m2).astype(np.float64) < thr)        # np.sqrt on float32 is correctly rounded, like sqrtf
+            got = ~(m2 < t2)
+        assert (ref == got).all(), (thr, t2, m2[ref != got][:4])
+
+
+def test_bins_sort_orders_by_address_and_returns_the_walk_positions():
+    """tfft_bins_sort: strictly increasing (plane, y, x) keys (the walk never repeats a bin), sorted[i] ==
+    walk[bit_index[i]], bit_index a permutation; degenerate sizes."""
+    import steganosaurus_amd as S
+    key = hashlib.sha256(b"sort").digest()
+    for (ph, pw, n) in ((256, 256, 2480), (512, 2048, 30000), (64, 64, 1), (64, 64, 0)):
+        bins = S.Walk(key, ph, pw).next(n)
+        sb, idx = S.bins_sort(bins)
+        assert sb.dtype == S.BIN_DTYPE and len(sb) == n and idx.dtype == np.uint32
+        assert np.array_equal(sb, bins[idx]) and np.array_equal(np.sort(idx), np.arange(n))
+        k = (sb["plane"].astype(np.int64) << 32) | (sb["y"].astype(np.int64) << 16) | sb["x"]
+        assert (np.diff(k) > 0).all()
+    # duplicates keep their walk order (stable): a synthetic list
+    b = np.zeros(6, S.BIN_DTYPE); b["x"] = [5, 3, 5, 3, 1, 5]; b["y"] = 7; b["plane"] = [1, 0, 1, 0, 2, 0]
+    sb, idx = S.bins_sort(b)
+    assert idx.tolist() == [1, 3, 5, 0, 2, 4]

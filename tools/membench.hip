@@ -17,6 +17,22 @@ __global__ void k_copy(const float4* __restrict__ in, float4* __restrict__ out, 
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// read-only stream (the shape of the median / capacity passes): U independent 16-byte loads per thread per
+// iteration, grid-stride; the sum keeps the loads alive
+template <int U>
+__global__ void k_read(const float4* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (i + u * stride < n) ? in[i + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 // LB = bytes per lane (8 or 16).  tile = blockIdx.x (column tile), blockIdx.y = row group, blockIdx.z = plane
 template <int LB>
 __global__ void k_tile(const char* __restrict__ in, char* __restrict__ out, int rows, size_t pitch, int seg,
@@ -58,6 +74,26 @@ int main() {
         for (int i = 0; i < 5; i++) k_copy<<<2048, 256>>>((const float4*)a, (float4*)b, big / 16);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         if (rep) printf("copy 1.5 GiB          : %7.1f GB/s\n", 5 * 2.0 * big / time_ms(e0, e1) / 1e6);
+    }
+    {
+        float* sink; CK(hipMalloc(&sink, 4));
+        const int grids[] = {1024, 2048, 4096, 8192, 16384};
+        for (int g : grids) {
+            float r[3];
+            for (int v = 0; v < 3; v++) {
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 5; i++) {
+                        if (v == 0) k_read<1><<<g, 256>>>((const float4*)a, sink, big / 16);
+                        if (v == 1) k_read<4><<<g, 256>>>((const float4*)a, sink, big / 16);
+                        if (v == 2) k_read<8><<<g, 256>>>((const float4*)a, sink, big / 16);
+                    }
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    r[v] = 5.0 * big / time_ms(e0, e1) / 1e6;
+                }
+            }
+            printf("read-only 1.5 GiB grid %5d x256: unroll 1 %7.1f  unroll 4 %7.1f  unroll 8 %7.1f GB/s\n", g, r[0], r[1], r[2]);
+        }
     }
     // planes of 4096 rows x 16 KiB (= 2048 float2): 64 MiB per plane
     const int rows = 4096; const size_t pitch = 16384; const size_t plane = rows * pitch;
