@@ -25,6 +25,14 @@
 #include "tfft_fft.h"
 #include "tfft_kernels.h"
 
+// occupancy floor for a kernel: the register allocator must fit n waves per SIMD (512/n VGPRs)
+#ifndef TFFT_WAVES_PER_EU
+#define TFFT_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+#ifndef TFFT_ROWS_LAZY_LOG
+#define TFFT_ROWS_LAZY_LOG 11
+#endif
+
 namespace tfft {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tfft_smem[];
@@ -32,6 +40,17 @@ extern __shared__ __attribute__((aligned(16))) unsigned char tfft_smem[];
 // |F| exactly as every kernel of this library computes it (one definition so
 // that medians, capacity and embed agree bit for bit)
 __device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
+
+// The four samples of colour plane p (0..2) in one 12-byte group of four RGB pixels a|b|c: bytes p, p+3,
+// p+6, p+9.  Two byte-aligned 32-bit windows hold them at byte 0 and byte 3 (v_alignbyte_b32 takes its
+// shift modulo 4, hence the select for p == 2), and byte -> float is one v_cvt_f32_ubyteN each: ~10
+// instructions per group instead of ~40 for variable 64-bit shifts.
+__device__ __forceinline__ void plane_samples4(uint32_t a, uint32_t b, uint32_t c, int p, float& v0, float& v1, float& v2, float& v3) {
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(b, a, (uint32_t)p);                         // bytes p .. p+3
+    const uint32_t w1 = (p == 2) ? c : __builtin_amdgcn_alignbyte(c, b, (uint32_t)(p + 2));    // bytes p+6 .. p+9
+    v0 = (float)(w0 & 0xFFu); v1 = (float)(w0 >> 24);
+    v2 = (float)(w1 & 0xFFu); v3 = (float)(w1 >> 24);
+}
 
 // ---------------------------------------------------------------------------
 // rows, forward: u8 RGB row -> (optional centring) -> zero-pad -> real FFT of
@@ -44,7 +63,8 @@ __device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, 
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)   T = M/E
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
+__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
+k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
@@ -66,15 +86,24 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
         // one plane per workgroup: the same 12-byte groups, keeping the four samples of this plane
         const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
         const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
-        const int sh = 8 * plane0;      // byte lane of this plane inside a pixel
-        for (int g = tid; g < (P.W >> 2); g += nthr) {
-            const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];
-            const uint64_t lo = ((uint64_t)b << 32) | a;                 // bytes 0..7
-            const uint64_t hi = ((uint64_t)c << 32) | b;                 // bytes 4..11
-            const float v0 = (float)((lo >> sh) & 0xFF), v1 = (float)((lo >> (sh + 24)) & 0xFF);
-            const float v2 = (float)((hi >> (sh + 16)) & 0xFF), v3 = (float)((hi >> (sh + 40)) & 0xFF);
-            lds[lay.idx(2 * g, 0)] = make_float2(s0 * v0, s1 * v1);
-            lds[lay.idx(2 * g + 1, 0)] = make_float2(s0 * v2, s1 * v3);
+        // all loads first, then the conversions (see k_rowcol_fwd): E/2 four-pixel groups per thread
+        constexpr int GMAX = (E + 1) / 2;
+        const int ng = P.W >> 2;
+        uint32_t ra[GMAX], rb[GMAX], rc[GMAX];
+#pragma unroll
+        for (int i = 0; i < GMAX; i++) {
+            const int g = imin(tid + i * nthr, ng - 1);      // clamped, not predicated: a branch per load serialises them
+            ra[i] = srcw[3 * g]; rb[i] = srcw[3 * g + 1]; rc[i] = srcw[3 * g + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < GMAX; i++) {
+            const int g = tid + i * nthr;
+            if (g < ng) {
+                float v0, v1, v2, v3;
+                plane_samples4(ra[i], rb[i], rc[i], plane0, v0, v1, v2, v3);
+                lds[lay.idx(2 * g, 0)] = make_float2(s0 * v0, s1 * v1);
+                lds[lay.idx(2 * g + 1, 0)] = make_float2(s0 * v2, s1 * v3);
+            }
         }
         for (int m = (P.W >> 1) + tid; m < M; m += nthr) lds[lay.idx(m, 0)] = make_float2(0.f, 0.f);
     } else if (fast) {
@@ -120,8 +149,12 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
     }
     // twiddles of the radix passes and of the real-FFT split (indices depend on the thread only):
     // issued before the barrier so their L2 latency overlaps the staging
-    float2 W[tw_regs<M, E>()];
-    fft_prefetch_twiddles<M, E, +1>(W, t, tw, 2);
+    // Rows of 4096 and more samples (two or more waves per row): the prefetched pass twiddles cost 54
+    // registers, which at 171 VGPRs leaves two waves per SIMD; fetched at the point of use the kernel fits
+    // four, and the extra occupancy hides more latency than the prefetch did.
+    constexpr bool LAZY = LOGM >= TFFT_ROWS_LAZY_LOG;
+    float2 W[LAZY ? 1 : tw_regs<M, E>()];
+    if (!LAZY) fft_prefetch_twiddles<M, E, +1>(W, t, tw, 2);
     constexpr int NSPLIT = (M / 2) / T + 1;
     float2 wk[NSPLIT];
 #pragma unroll
@@ -134,7 +167,8 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
 #pragma unroll
     for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, pb)];
     Sync::sync();
-    fft_block<M, E, +1, Sync>(u, lds, lay, t, pb, W);
+    if (LAZY) fft_block_lazy<M, E, +1, Sync>(u, lds, lay, t, pb, tw, 2);
+    else fft_block<M, E, +1, Sync>(u, lds, lay, t, pb, W);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = u[m];
     Sync::sync();
@@ -200,12 +234,26 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
         if (((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0)) {
             const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
             const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
-            const int sh = 8 * plane;
-            for (int g = t; g < (P.W >> 2); g += T) {
-                const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];
-                const uint64_t lo = ((uint64_t)b << 32) | a, hi = ((uint64_t)c << 32) | b;
-                lds[lay.idx(2 * g, n1)] = make_float2(s0 * (float)((lo >> sh) & 0xFF), s1 * (float)((lo >> (sh + 24)) & 0xFF));
-                lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * (float)((hi >> (sh + 16)) & 0xFF), s1 * (float)((hi >> (sh + 40)) & 0xFF));
+            // ALL of the row's loads are issued before the first conversion: a loop of load -> convert -> LDS
+            // store exposes one memory round trip per iteration (8 of them), which was the largest single
+            // cost of this kernel (skipping the loads alone took 0.26 of 0.80 ms in a phase-skipping run)
+            constexpr int GMAX = (2 * M / 4) / T;       // 4-pixel groups per lane
+            const int ng = P.W >> 2;
+            uint32_t ra[GMAX], rb[GMAX], rc[GMAX];
+#pragma unroll
+            for (int i = 0; i < GMAX; i++) {
+                const int g = imin(t + i * T, ng - 1);       // clamped, not predicated: a branch per load serialises them (s_waitcnt in every arm)
+                ra[i] = srcw[3 * g]; rb[i] = srcw[3 * g + 1]; rc[i] = srcw[3 * g + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < GMAX; i++) {
+                const int g = t + i * T;
+                if (g < ng) {
+                    float v0, v1, v2, v3;
+                    plane_samples4(ra[i], rb[i], rc[i], plane, v0, v1, v2, v3);
+                    lds[lay.idx(2 * g, n1)] = make_float2(s0 * v0, s1 * v1);
+                    lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * v2, s1 * v3);
+                }
             }
             for (int m = (P.W >> 1) + t; m < M; m += T) lds[lay.idx(m, n1)] = make_float2(0.f, 0.f);
         } else {
@@ -286,6 +334,8 @@ __device__ __forceinline__ unsigned quantise_u8(float v) {
 //   grid (N2, 3, n_images)   block (64, N1)   M = 1024, E = 16
 // ---------------------------------------------------------------------------
 template <int LOGN1>
+// (140 VGPRs leave one workgroup of 8 waves per CU; forcing 128 with amdgpu_waves_per_eu(4) spills 19 dwords and
+// measured 0.71 ms against 0.58 ms)
 __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
                              const float2* __restrict__ tw, RowParams P) {
     constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
@@ -358,7 +408,8 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
+__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
+k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
@@ -374,8 +425,9 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
     float2 xin[E];
 #pragma unroll
     for (int m = 0; m < E; m++) xin[m] = src[t + m * T];
-    float2 W[tw_regs<M, E>()];
-    fft_prefetch_twiddles<M, E, -1>(W, t, tw, 2);
+    constexpr bool LAZY = LOGM >= TFFT_ROWS_LAZY_LOG;      // see k_rows_fwd
+    float2 W[LAZY ? 1 : tw_regs<M, E>()];
+    if (!LAZY) fft_prefetch_twiddles<M, E, -1>(W, t, tw, 2);
     float2 wk[E];
 #pragma unroll
     for (int m = 0; m < E; m++) wk[m] = tw[t + m * T];
@@ -400,7 +452,8 @@ __global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) k_ro
         }
     }
     Sync::sync();
-    fft_block<M, E, -1, Sync>(u, lds, lay, t, pb, W);
+    if (LAZY) fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, pb, tw, 2);
+    else fft_block<M, E, -1, Sync>(u, lds, lay, t, pb, W);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = cscale(u[m], P.scale);
     __syncthreads();

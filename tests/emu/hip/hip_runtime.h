@@ -24,6 +24,7 @@
 #define __shared__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define TFFT_WAVES_PER_EU(n)
 
 struct float2 { float x, y; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
@@ -59,6 +60,8 @@ unsigned emu_lane();
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline unsigned emu_mbcnt_lo(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (unsigned)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
 static inline unsigned emu_mbcnt_hi(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (l < 32 ? 0u : (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u))); }
+static inline unsigned emu_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }
+#define __builtin_amdgcn_alignbyte(hi, lo, sh) emu_alignbyte((hi), (lo), (sh))
 #define __builtin_amdgcn_mbcnt_lo(m, i) emu_mbcnt_lo((m), (i))
 #define __builtin_amdgcn_mbcnt_hi(m, i) emu_mbcnt_hi((m), (i))
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
