@@ -220,48 +220,58 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     // pass twiddles exp(+2 pi i j/M), j < M, staged once per workgroup behind the row slabs: the radix
     // passes then read them with LDS latency instead of L2 latency (8 KB; two workgroups still fit a CU)
     float2* ltw = lds + (size_t)N1 * lay.pitch;
-    for (int j = n1 * T + t; j < M; j += T * N1) ltw[j] = tw[2 * j];
+    float2* lwc = ltw + M;              // + the N1 column-step twiddles exp(+2 pi i n2 k1/PH) of this workgroup
 
+    // ---- every global load of the prologue is issued before the first LDS store that needs one of them:
+    // s_waitcnt counts in order, so a store placed between two groups of loads makes the second group
+    // wait a full memory round trip for the first (table fill loop, per-iteration staging loads and the
+    // column twiddles after the barrier each cost ~1 us per workgroup that way)
+    constexpr int NT = M / (T * N1);
+    float2 tv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) tv[i] = tw[2 * (n1 * T + t + i * T * N1)];
+    float2 cv = make_float2(0.f, 0.f);
+    if (n1 == 0 && t < N1) cv = tw_h[(n2 * t) & (P.PH - 1)];
     constexpr int NSPLIT = (M / 2) / T + 1;
-    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW): lane-only indices, fetched before the staging
+    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW): lane-only indices
     if (live) {
 #pragma unroll
         for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
     }
-    if (live) {
-        const int nbytes = P.W * 3;
-        const uint8_t* src = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
-        if (((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0)) {
-            const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
-            const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
-            // ALL of the row's loads are issued before the first conversion: a loop of load -> convert -> LDS
-            // store exposes one memory round trip per iteration (8 of them), which was the largest single
-            // cost of this kernel (skipping the loads alone took 0.26 of 0.80 ms in a phase-skipping run)
-            constexpr int GMAX = (2 * M / 4) / T;       // 4-pixel groups per lane
-            const int ng = P.W >> 2;
-            uint32_t ra[GMAX], rb[GMAX], rc[GMAX];
+    const uint8_t* src = rgb + ((size_t)img * P.H + (live ? y : 0)) * (size_t)(P.W * 3);
+    const bool fastp = live && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    constexpr int GMAX = (2 * M / 4) / T;               // 4-pixel groups per lane
+    const int ng = P.W >> 2;
+    uint32_t ra[GMAX], rb[GMAX], rc[GMAX];
+    if (fastp) {
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
 #pragma unroll
-            for (int i = 0; i < GMAX; i++) {
-                const int g = imin(t + i * T, ng - 1);       // clamped, not predicated: a branch per load serialises them (s_waitcnt in every arm)
-                ra[i] = srcw[3 * g]; rb[i] = srcw[3 * g + 1]; rc[i] = srcw[3 * g + 2];
-            }
+        for (int i = 0; i < GMAX; i++) {
+            const int g = imin(t + i * T, ng - 1);      // clamped, not predicated: a branch per load serialises them (s_waitcnt in every arm)
+            ra[i] = srcw[3 * g]; rb[i] = srcw[3 * g + 1]; rc[i] = srcw[3 * g + 2];
+        }
+    }
 #pragma unroll
-            for (int i = 0; i < GMAX; i++) {
-                const int g = t + i * T;
-                if (g < ng) {
-                    float v0, v1, v2, v3;
-                    plane_samples4(ra[i], rb[i], rc[i], plane, v0, v1, v2, v3);
-                    lds[lay.idx(2 * g, n1)] = make_float2(s0 * v0, s1 * v1);
-                    lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * v2, s1 * v3);
-                }
+    for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
+    if (n1 == 0 && t < N1) lwc[t] = cv;
+    if (fastp) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+#pragma unroll
+        for (int i = 0; i < GMAX; i++) {
+            const int g = t + i * T;
+            if (g < ng) {
+                float v0, v1, v2, v3;
+                plane_samples4(ra[i], rb[i], rc[i], plane, v0, v1, v2, v3);
+                lds[lay.idx(2 * g, n1)] = make_float2(s0 * v0, s1 * v1);
+                lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * v2, s1 * v3);
             }
-            for (int m = (P.W >> 1) + t; m < M; m += T) lds[lay.idx(m, n1)] = make_float2(0.f, 0.f);
-        } else {
-            for (int n = t; n < 2 * M; n += T) {
-                float v = 0.0f;
-                if (n < P.W) { v = (float)src[3 * n + plane]; if (P.center && ((n + y) & 1)) v = -v; }
-                ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
-            }
+        }
+        for (int m = (P.W >> 1) + t; m < M; m += T) lds[lay.idx(m, n1)] = make_float2(0.f, 0.f);
+    } else if (live) {
+        for (int n = t; n < 2 * M; n += T) {
+            float v = 0.0f;
+            if (n < P.W) { v = (float)src[3 * n + plane]; if (P.center && ((n + y) & 1)) v = -v; }
+            ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
         }
     }
     __syncthreads();                    // the twiddle table and every live row are staged
@@ -301,9 +311,9 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     __syncthreads();
 
     // ---- length-N1 DFT across the rows, per column; output row k1*N2 + n2, times exp(+2 pi i n2 k1/PH)
-    float2 wc[N1];
-#pragma unroll
-    for (int k1 = 0; k1 < N1; k1++) wc[k1] = tw_h[(n2 * k1) & (P.PH - 1)];
+    float2 wc[N1];                      // from the LDS copy made at the top: as global loads here they were a
+#pragma unroll                          // full memory round trip between the barrier and the first store
+    for (int k1 = 0; k1 < N1; k1++) wc[k1] = lwc[k1];
     float2* dst = out + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
     for (int x = n1 * T + t; x < M; x += T * N1) {
         float2 v[N1];
@@ -347,6 +357,22 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
     LayRows lay{LayRows::padded(M)};
 
+    // pass twiddles exp(+2 pi i j/M) staged in LDS behind the row slabs (as in k_rowcol_fwd): LDS reads need
+    // no 64-bit address pair per twiddle, which is what kept this kernel above 128 VGPRs (one workgroup per CU)
+    float2* ltw = lds + (size_t)N1 * lay.pitch;
+    constexpr int NT = M / (T * N1);    // stored to LDS after the column loads have been issued (see k_rowcol_fwd)
+    float2 tv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) tv[i] = tw[2 * (n1 * T + t + i * T * N1)];
+
+    // split twiddles exp(+2 pi i k/PW) of this lane's bins, fetched ahead of the column phase: the kernel sits
+    // at one workgroup per CU either way (140..168 VGPRs), so the 32 registers are free
+    float2 wsp[E];
+    if (y < P.H) {
+#pragma unroll
+        for (int m = 0; m < E; m++) wsp[m] = tw[t + m * T];
+    }
+
     // ---- length-N1 inverse DFT across the rows, per column
     const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
     for (int x = n1 * T + t; x < M; x += T * N1) {
@@ -357,27 +383,29 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
 #pragma unroll
         for (int r = 0; r < N1; r++) lds[lay.idx(x, r)] = v[bitrev(r, LOGN1)];
     }
+#pragma unroll
+    for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
     __syncthreads();
     if (y >= P.H) return;               // wave uniform (one wave per row); no barrier follows
 
     // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
+    // branch-free, the packed bin k == 0 (lane 0, m == 0) included: as a divergent branch its twiddle load
+    // was followed by s_waitcnt vmcnt(0) -- one full memory round trip before the other 15 loads were issued
     float2 u[E];
 #pragma unroll
     for (int m = 0; m < E; m++) {
         const int k = t + m * T;
         const float2 xk = lds[lay.idx(k, n1)];
-        if (k == 0) {
-            u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));
-        } else {
-            const float2 xm = lds[lay.idx(M - k, n1)];
-            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(tw[k]));      // fetched here: prefetching 16 more registers costs a workgroup per CU
-            u[m] = make_float2(ev.x - od.y, ev.y + od.x);
-        }
+        const float2 xm = lds[lay.idx((M - k) & (M - 1), n1)];
+        const float2 w = wsp[m];
+        const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+        const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+        const float2 od = cmul(d, cconj(w));
+        u[m] = make_float2(ev.x - od.y, ev.y + od.x);
+        if (m == 0 && k == 0) u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));   // X[0], X[M] packed in bin 0
     }
     WaveSync::sync();
-    fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, tw, 2);
+    fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
     WaveSync::sync();
@@ -1179,7 +1207,7 @@ hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw,
 hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
                              int n_images, hipStream_t s) {
     constexpr int LOGN1 = 3;
-    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024) * sizeof(float2);    // row slabs + twiddle table
+    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024 + (1 << LOGN1)) * sizeof(float2);    // row slabs + twiddle tables
     auto k = k_rowcol_fwd<LOGN1>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1188,7 +1216,7 @@ hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_p
 }
 hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
     constexpr int LOGN1 = 3;
-    const size_t lds = (size_t)(1 << LOGN1) * LayRows::padded(1024) * sizeof(float2);
+    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024) * sizeof(float2);    // row slabs + twiddle table
     auto k = k_colrow_inv<LOGN1>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
