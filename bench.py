@@ -64,7 +64,7 @@ def fused_plan(w, h):
     return max(2, next_pow2(w)) == 2048 and next_pow2(h) >= 128 and os.environ.get("TFFT_FUSE", "1") != "0"
 
 
-def kernel_bytes(stage, w, h, n_bits, two_step):
+def kernel_bytes(stage, w, h, n_bits, two_step, read_rows_frac=1.0):
     """Compulsory HBM bytes of each kernel in THIS implementation's layout (half spectrum,
     rows >= H skipped where the data is known to be zero / not needed).  DESIGN.md section 4."""
     PW, PH = max(2, next_pow2(w)), next_pow2(h)
@@ -91,6 +91,8 @@ def kernel_bytes(stage, w, h, n_bits, two_step):
         "read": n_bits * (8 + 8 + 1),
         "medians": 3 * 3 * plane_full,
         "capacity": 0,
+        # final forward column step of the extract path: reads everything, stores the rows the bin list touches
+        "cols_fwd_read": int(3 * plane_full + 3 * plane_full * read_rows_frac),
     }[stage]
 
 
@@ -114,6 +116,7 @@ def algorithmic_bytes(stage, w, h, n_bits, two_step):
         "cols_inv_b": 0 if fused else (col // 2 if split else 0),
         "embed": 40 * n_bits, "read": 16 * n_bits,
         "medians": 0, "capacity": 0,        # not in the 8(d) model: their time counts against the path fraction only
+        "cols_fwd_read": col if fused else (col // 2 if split else col),      # the final forward column step, extraction's variant
     }[stage]
 
 
@@ -313,7 +316,10 @@ def main():
         # the two-step column stages work in place, so repeating one of them destroys its input: time the
         # forward stages first, rebuild a clean spectrum, then time everything that reads the spectrum, and
         # the inverse stages last
-        order = [0, 1, 2, "clean", 8, 9, 3, 7, 4, 5, 6]
+        order = [0, 1, 2, 10, "clean", 8, 9, 3, 7, 4, 5, 6]
+        hb = bins if rank == 0 else None
+        last_row = int(np.where(hb["x"] <= PW // 2, hb["y"], (PH - hb["y"].astype(np.int64)) % PH).max())
+        rows_frac = (last_row + 1) / PH
         for sid in order:
             if sid == "clean":
                 for k in (0, 1, 2):
@@ -323,7 +329,7 @@ def main():
             ms, nl = prof(sid, args.stage_reps)
             if nl == 0:
                 continue
-            kb = kernel_bytes(name, W, H, n_bits, two_step) * slots
+            kb = kernel_bytes(name, W, H, n_bits, two_step, rows_frac) * slots
             ab = algorithmic_bytes(name, W, H, n_bits, two_step) * slots
             stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots,
                             "algorithmic_bytes": ab, "algorithmic_GBs": round(ab / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,

@@ -293,7 +293,7 @@ class Context:
                                                n_bits, alpha, _ptr(bits_out_ptr)), "tfft_extract_batch_dev")
 
     STAGES = ["rows_fwd", "cols_fwd_a", "cols_fwd_b", "embed", "cols_inv_a", "cols_inv_b", "rows_inv", "read",
-              "medians", "capacity"]
+              "medians", "capacity", "cols_fwd_read"]
 
     def profile_stage(self, stage, reps, rgb_ptr=None, out_ptr=None, bins_ptr=None, bits_ptr=None, bits_out_ptr=None,
                       n_bits=0, alpha=0.5, n_images=1):

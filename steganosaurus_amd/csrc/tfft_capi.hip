@@ -56,6 +56,8 @@ struct tfft_ctx {
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS]
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
+    int* last_row = nullptr;              // device scalar of k_bins_last_row
+    const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
     uint32_t* bit_index = nullptr;        // tfft_set_bit_index: bins[i] carries stream bit bit_index[i]
     uint64_t bit_index_n = 0;
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
@@ -140,7 +142,9 @@ int set_geometry(tfft_ctx* c, Slot& s, int w, int h, int center) {
 //   forward : ROWS_FWD (u8 -> tmp), COLS_FWD_A (tmp -> tmp | spec), COLS_FWD_B (tmp -> spec, two-step only)
 //   inverse : COLS_INV_A (spec -> tmp), COLS_INV_B (tmp -> tmp, two-step only), ROWS_INV (tmp -> u8)
 enum Stage { ROWS_FWD = 0, COLS_FWD_A = 1, COLS_FWD_B = 2, EMBED = 3, COLS_INV_A = 4, COLS_INV_B = 5, ROWS_INV = 6,
-             READ = 7, MEDIANS = 8, CAPACITY = 9, N_STAGES = 10 };
+             READ = 7, MEDIANS = 8, CAPACITY = 9,
+             COLS_FWD_READ = 10,      // the final forward column step as extraction runs it (rows above the bin list's last row not stored)
+             N_STAGES = 11 };
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
@@ -165,6 +169,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             if (pl.fused_fwd) return TFFT_OK;       // done inside ROWS_FWD
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
+                cp.last_row_dev = c->fwd_last_row;
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
@@ -175,6 +180,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             if (pl.direct) return TFFT_OK;
             // for every k1: length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
             cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
+            cp.last_row_dev = c->fwd_last_row;
             HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
@@ -346,6 +352,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->partial, ns * 3 * TFFT_STAT_MAX_BLOCKS * sizeof(unsigned));
     if (!rc) rc = dev_alloc(c, (void**)&c->usable, ns * sizeof(unsigned long long));
     if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
+    if (!rc) rc = dev_alloc(c, (void**)&c->last_row, sizeof(int));
     if (!rc && hipMemset(c->err, 0, sizeof(int)) != hipSuccess) rc = TFFT_E_HIP;
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = TFFT_E_HIP;
     if (rc != TFFT_OK) { tfft_destroy(c); return rc; }
@@ -358,7 +365,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
     (void)hipFree(c->out_pool);
@@ -604,10 +611,15 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
                          double alpha, uint8_t* bits_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+    // the spectrum is only read at the bins of the list: rows above the highest one are never stored
+    HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, c->last_row, st));
+    c->fwd_last_row = c->last_row;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
+    c->fwd_last_row = nullptr;
     if (rc) return rc;
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
     HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
+    for (int i = 0; i < g; i++) c->slots[s0 + i].has_spec = false;      // partial spectrum: not for tfft_medians & co
     return TFFT_OK;
 }
 
@@ -757,14 +769,24 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
     if (stage == MEDIANS) launches = c->median_force_fallback ? 7 : 13;
     if (stage == CAPACITY) launches = 2;
+    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
     if (launches == 0) return TFFT_OK;
     { const float2* t; int rc = get_twiddles(c, s.PWi, &t); if (rc) return rc; rc = get_twiddles(c, s.PH, &t); if (rc) return rc; }
+    if (stage == COLS_FWD_READ) {
+        if (!bins_dev) return TFFT_E_INVALID;
+        HIPCHK(c, launch_bins_last_row((const tfft_bin*)bins_dev, n_bits, s.PH, s.PWi, c->last_row, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {
         int rc = TFFT_OK;
         switch (stage) {
+            case COLS_FWD_READ:
+                c->fwd_last_row = c->last_row;
+                rc = enqueue_fft_stage(c, 0, n_images, final_fwd, nullptr, nullptr, c->stream);
+                c->fwd_last_row = nullptr;
+                break;
             case EMBED: {
                 if (!index_ok(c, n_bits)) return TFFT_E_STATE;
                 EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);

@@ -25,6 +25,8 @@ struct ColParams {
     int out_a, out_b;  // output row = out_a*k + out_b*g
     int in_rows;       // input rows >= in_rows are zero (not loaded)
     int out_rows;      // output rows >= out_rows are not stored
+    const int* last_row_dev;   // optional device scalar: rows > *last_row_dev are not stored either (extraction reads
+                               // only the rows its bin list touches; k_bins_last_row)
     int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)
     int tiles_per_block;  // adjacent 16-column tiles walked by one workgroup
     size_t plane_stride;  // float2 elements between planes (PH*M)
@@ -91,6 +93,8 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
                            hipStream_t s);
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s);
+// highest stored row any bin of the list touches -> *last_row (device int, reset here)
+hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
                         const EmbedParams& P, int n_images, int* err, hipStream_t s);
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,

@@ -565,6 +565,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             v[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
         }
     };
+    const int out_rows = P.last_row_dev ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     float2 u[E], un[E];
     load_tile(tile0, u);
     float2 W[tw_regs<L, E>()];
@@ -584,7 +585,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             for (int m = 0; m < E; m++) {
                 const int k = t + m * T;
                 const int row = P.out_a * k + P.out_b * g;
-                if (row < P.out_rows) {
+                if (row < out_rows) {
                     float2 v = u[m];
                     if (P.tw_out) v = cmul(v, wo[m]);
                     dst[(size_t)row * P.M] = v;
@@ -621,6 +622,26 @@ __device__ __forceinline__ float2 full_bin(const float2* __restrict__ plane, int
     }
     if (x < M) return plane[(size_t)y * M + x];
     return cconj(plane[(size_t)((PH - y) & (PH - 1)) * M + (PW - x)]);
+}
+
+// Highest row of the stored half spectrum that a bin list touches (bins with x > M live in row PH-y of
+// the mirror half).  The read path lets the last forward column step skip the stores of every row above
+// it: with the default annulus (rmax = 0.45) that is 55 % of the rows.
+__global__ void k_bins_last_row(const tfft_bin* __restrict__ bins, uint64_t n, int PH, int PW, int* __restrict__ last_row) {
+    int* blk = reinterpret_cast<int*>(tfft_smem);
+    if (threadIdx.x == 0) blk[0] = 0;
+    __syncthreads();
+    int mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const tfft_bin bn = bins[i];
+        const int x = bn.x, y = bn.y;
+        if (x >= PW || y >= PH) continue;           // k_read flags these
+        const int row = (x <= (PW >> 1)) ? y : ((PH - y) & (PH - 1));
+        mine = row > mine ? row : mine;
+    }
+    if (mine) atomicMax(&blk[0], mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk[0]) atomicMax(last_row, blk[0]);
 }
 
 // write_bit_on_bin S:712-732 over a bin list (the loop body of S:1074-1097).
@@ -1261,6 +1282,14 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     return hipSuccess;
 }
 
+hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(last_row, 0, sizeof(int), s);
+    if (e != hipSuccess || n == 0) return e;
+    unsigned nb = (unsigned)((n + 2047) / 2048);
+    if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(k_bins_last_row, dim3(nb), dim3(256), 16, s, bins, n, PH, PW, last_row);
+    return hipGetLastError();
+}
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
                         const EmbedParams& P, int n_images, int* err, hipStream_t s) {
     if (P.n == 0 || n_images == 0) return hipSuccess;
