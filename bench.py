@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="resident images per launch (default: the whole per-GPU batch, at most 32)")
     ap.add_argument("--no-stats", action="store_true", help="skip medians+capacity inside embed (not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-only", action="store_true",
+                    help="profiling runs: skip the single-image and host-buffer legs so that every traced launch is a batched one")
     ap.add_argument("--stage-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -284,7 +286,7 @@ def main():
     # ---- the same round trip on ONE image at a time (BASELINE configs[1] is phrased on a single image):
     # launch/latency bound, reported beside the batched headline, never instead of it
     single = None
-    if rank == 0 and n_img > 1:
+    if rank == 0 and n_img > 1 and not args.batched_only:
         def one():
             ctx.embed_batch_dev(1, d_img.data_ptr(), W, H, d_bins.data_ptr(), d_bits.data_ptr(), n_bits, d_stego.data_ptr(),
                                 usable_ptr=None if args.no_stats else d_usable.data_ptr())
@@ -358,7 +360,7 @@ def main():
                                   "is why `achieved` can exceed what the HBM counters (`traffic`, bytes per launch) show" % args.stage_reps}
         out["stages"] = stages
 
-        if world == 1:
+        if world == 1 and not args.batched_only:
             # side figure, never `value`: the same step when the caller hands over HOST buffers (pinned):
             # tfft_embed_batch / tfft_extract_batch overlap the PCIe copies with the kernels on three streams
             h_img = torch.from_numpy(covers).pin_memory()

@@ -1328,7 +1328,22 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         unsigned nbs = (unsigned)((PH + step - 1) / step); if (nbs > nb) nbs = nb; if (nbs < 1) nbs = 1;
         hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
         hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st);
-        unsigned nbc = (unsigned)((PH + 3) / 4); if (nbc > nb) nbc = nb; if (nbc < 1) nbc = 1;
+        // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
+        // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
+        // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
+        static int resident = 0, cus = 0;
+        if (!resident) {
+            int dev = 0, r = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_collect_bracket, 256, (1024 + 4 * 512 + 8) * sizeof(unsigned)) != hipSuccess) r = 0;
+            resident = r > 0 ? r : 4;
+            if (cus <= 0) cus = 256;
+        }
+        unsigned nbc = (unsigned)(((long long)cus * resident) / (3LL * n_images));
+        if (nbc > (unsigned)((PH + 3) / 4)) nbc = (unsigned)((PH + 3) / 4);
+        if (nbc > TFFT_STAT_MAX_BLOCKS) nbc = TFFT_STAT_MAX_BLOCKS;
+        if (nbc < 1) nbc = 1;
         hipLaunchKernelGGL(k_collect_bracket, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                            img_stride, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
