@@ -56,7 +56,10 @@ struct tfft_ctx {
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS]
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
-    int* last_row = nullptr;              // device scalar of k_bins_last_row
+    int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
+    hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_streams = 1;
     const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
     uint32_t* bit_index = nullptr;        // tfft_set_bit_index: bins[i] carries stream bit bit_index[i]
     uint64_t bit_index_n = 0;
@@ -331,6 +334,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
+    if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
@@ -352,7 +356,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->partial, ns * 3 * TFFT_STAT_MAX_BLOCKS * sizeof(unsigned));
     if (!rc) rc = dev_alloc(c, (void**)&c->usable, ns * sizeof(unsigned long long));
     if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
-    if (!rc) rc = dev_alloc(c, (void**)&c->last_row, sizeof(int));
+    if (!rc) rc = dev_alloc(c, (void**)&c->last_row, 2 * sizeof(int));
     if (!rc && hipMemset(c->err, 0, sizeof(int)) != hipSuccess) rc = TFFT_E_HIP;
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = TFFT_E_HIP;
     if (rc != TFFT_OK) { tfft_destroy(c); return rc; }
@@ -371,6 +375,9 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipFree(c->out_pool);
     for (int i = 0; i < 4; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
@@ -612,14 +619,37 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     // the spectrum is only read at the bins of the list: rows above the highest one are never stored
-    HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, c->last_row, st));
-    c->fwd_last_row = c->last_row;
+    int* last_row = c->last_row + ((c->stream2 && st == c->stream2) ? 1 : 0);
+    HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
+    c->fwd_last_row = last_row;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
     c->fwd_last_row = nullptr;
     if (rc) return rc;
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
     HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
     for (int i = 0; i < g; i++) c->slots[s0 + i].has_spec = false;      // partial spectrum: not for tfft_medians & co
+    return TFFT_OK;
+}
+
+// TFFT_STREAMS=2: a chunk of >= 8 images is split in two halves that run on two HIP streams, so that the
+// latency-bound kernels of one half overlap the bandwidth-bound kernels of the other.  Returns the size of
+// the first half (0: no split) after forking stream2 off the context stream.
+static int split_fork(tfft_ctx* c, int g, int* h1) {
+    *h1 = 0;
+    if (c->n_streams < 2 || g < 8) return TFFT_OK;
+    if (!c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    *h1 = g / 2;
+    return TFFT_OK;
+}
+static int split_join(tfft_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return TFFT_OK;
 }
 
@@ -632,11 +662,18 @@ int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, 
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
         int rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        rc = embed_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev,
-                         (const uint8_t*)bits_dev + (size_t)i0 * n_bits, n_bits, alpha, rmin, rmax, magmin,
-                         usable_out_dev ? (unsigned long long*)usable_out_dev + i0 : nullptr,
-                         (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes, c->stream);
+        int h1 = 0;
+        rc = split_fork(c, g, &h1);
         if (rc) return rc;
+        for (int part = 0; part < (h1 ? 2 : 1); part++) {
+            const int s0 = part ? h1 : 0, gp = h1 ? (part ? g - h1 : h1) : g, i1 = i0 + s0;
+            rc = embed_chunk(c, s0, gp, (const uint8_t*)rgb_dev + (size_t)i1 * img_bytes, (const tfft_bin*)bins_dev,
+                             (const uint8_t*)bits_dev + (size_t)i1 * n_bits, n_bits, alpha, rmin, rmax, magmin,
+                             usable_out_dev ? (unsigned long long*)usable_out_dev + i1 : nullptr,
+                             (uint8_t*)rgb_out_dev + (size_t)i1 * img_bytes, part ? c->stream2 : c->stream);
+            if (rc) return rc;
+        }
+        if (h1) { rc = split_join(c); if (rc) return rc; }
     }
     return TFFT_OK;
 }
@@ -649,9 +686,16 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
         int rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        rc = extract_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, n_bits, alpha,
-                           (uint8_t*)bits_out_dev + (size_t)i0 * n_bits, c->stream);
+        int h1 = 0;
+        rc = split_fork(c, g, &h1);
         if (rc) return rc;
+        for (int part = 0; part < (h1 ? 2 : 1); part++) {
+            const int s0 = part ? h1 : 0, gp = h1 ? (part ? g - h1 : h1) : g, i1 = i0 + s0;
+            rc = extract_chunk(c, s0, gp, (const uint8_t*)rgb_dev + (size_t)i1 * img_bytes, (const tfft_bin*)bins_dev, n_bits, alpha,
+                               (uint8_t*)bits_out_dev + (size_t)i1 * n_bits, part ? c->stream2 : c->stream);
+            if (rc) return rc;
+        }
+        if (h1) { rc = split_join(c); if (rc) return rc; }
     }
     return TFFT_OK;
 }
