@@ -538,7 +538,9 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
 //   grid (ceil(M/16), ceil(G/GPB), n_planes)   block (16, T, GPB)
 // ---------------------------------------------------------------------------
 constexpr int cols_threads(int logl) { return imax(256, 16 * ((1 << logl) / elems_for(1 << logl))); }
-template <int LOGL, int SIGN>
+// ROWLIMIT: the extraction variant, rows above *P.last_row_dev are not stored (its own symbol, so that a
+// kernel trace tells the two apart)
+template <int LOGL, int SIGN, bool ROWLIMIT = false>
 __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             v[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
         }
     };
-    const int out_rows = P.last_row_dev ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
+    const int out_rows = ROWLIMIT ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     float2 u[E], un[E];
     load_tile(tile0, u);
     float2 W[tw_regs<L, E>()];
@@ -1253,7 +1255,7 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
     return hipSuccess;
 }
 
-template <int LOGL, int SIGN>
+template <int LOGL, int SIGN, bool ROWLIMIT = false>
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -1263,7 +1265,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const size_t lds = (size_t)gpb * L * C * sizeof(float2);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
-    auto k = k_fft_cols<LOGL, SIGN>;
+    auto k = k_fft_cols<LOGL, SIGN, ROWLIMIT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1274,9 +1276,11 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s) {
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
+    if (P.last_row_dev && sign < 0) return hipErrorInvalidValue;      // the row limit exists for the forward direction only
 #define F(n)                                                                            \
-    return sign > 0 ? launch_cols_t<(n <= 10 ? n : 10), +1>(in, out, tw_ph, P, n_planes, s) \
-                    : launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s)
+    return sign < 0 ? launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s) \
+         : P.last_row_dev ? launch_cols_t<(n <= 10 ? n : 10), +1, true>(in, out, tw_ph, P, n_planes, s) \
+                          : launch_cols_t<(n <= 10 ? n : 10), +1>(in, out, tw_ph, P, n_planes, s)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
     return hipSuccess;
