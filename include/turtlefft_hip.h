@@ -130,6 +130,21 @@ int tfft_inverse_rgb8_dev(tfft_ctx* ctx, int slot, void* rgb_out_dev);
  * floats, mirror half reconstructed by Hermitian symmetry.  Synchronises. */
 int tfft_download_spectrum(tfft_ctx* ctx, int slot, float* out);
 
+/* ---------------------------------------------------- fp64 audit transform
+ *   The reference's fft2d (S:341-366) evaluated in double on the
+ * device, operation by operation: bit reversal, radix-2 DIT stages, stage
+ * twiddles by the recurrence w *= wlen, no FMA contraction, rows then columns,
+ * inverse divided by n per dimension.  Its output equals the CPU reference bit
+ * for bit (checked against the oracle); it exists to measure the fp32 product
+ * path against the reference's arithmetic at sizes where the CPU takes minutes.
+ * Slow by design (one global pass per stage).  Host buffers; synchronises.
+ *   tfft_audit_fft2d_f64        in place on n_planes planes of ph x pw interleaved
+ *                               (re,im) doubles; ph, pw powers of two.
+ *   tfft_audit_forward_rgb8_f64 to_planes_u8 + apply_center + pad_to_fft + fft2d
+ *                               forward x3 (S:912-921): out = 3*PH*PW*2 doubles. */
+int tfft_audit_fft2d_f64(tfft_ctx* ctx, double* planes, int n_planes, int ph, int pw, int inverse);
+int tfft_audit_forward_rgb8_f64(tfft_ctx* ctx, const uint8_t* rgb, int w, int h, int center, double* out);
+
 /* ------------------------------------------------------------------ batches
  * n independent images of identical size sharing ONE bin list (the walk does
  * not depend on image content: S:797-799).  Images are processed in chunks of

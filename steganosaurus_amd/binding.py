@@ -60,6 +60,8 @@ SYMBOLS = {
     "tfft_walk_ks_blocks": (C.c_uint32, [_vp]),
     "tfft_walk_destroy": (_i, [_vp]),
     "tfft_walk_jitter": (_i, [C.c_char_p, _vp, _u64, _d, _vp]),
+    "tfft_audit_fft2d_f64": (_i, [_vp, _vp, _i, _i, _i, _i]),
+    "tfft_audit_forward_rgb8_f64": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tfft_bins_sort": (_i, [_vp, _vp, _u64]),
     "tfft_set_bit_index": (_i, [_vp, _vp, _u64]),
     "tfft_profile_stage": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _d, C.POINTER(C.c_float), _pi]),
@@ -275,6 +277,22 @@ class Context:
     def read_bins_dev(self, bins_ptr, n, out_ptr, alpha=0.5, slot=0):
         _check(self.lib.tfft_read_bins_dev(self.h, slot, _ptr(bins_ptr), None, n, alpha, 0, None, _ptr(out_ptr)),
                "tfft_read_bins_dev")
+
+    # ---- (f-4) fp64 audit transform: the reference's fft2d in double on the device ----------
+    def audit_fft2d_f64(self, planes, inverse=False):
+        """planes: (n, PH, PW) complex128; returns the transformed copy."""
+        a = np.ascontiguousarray(planes, np.complex128).copy()
+        n, ph, pw = a.shape
+        _check(self.lib.tfft_audit_fft2d_f64(self.h, _ptr(a), n, ph, pw, int(inverse)), "tfft_audit_fft2d_f64")
+        return a
+
+    def audit_forward_rgb8_f64(self, rgb, center=False):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w = rgb.shape[:2]
+        ph, pw = 1 << (h - 1).bit_length(), 1 << (w - 1).bit_length()
+        out = np.zeros((3, ph, pw), np.complex128)
+        _check(self.lib.tfft_audit_forward_rgb8_f64(self.h, _ptr(rgb), w, h, int(center), _ptr(out)), "tfft_audit_forward_rgb8_f64")
+        return out
 
     def download_spectrum(self, pw, ph, slot=0):
         out = np.zeros((3, ph, pw), np.complex64)

@@ -862,6 +862,45 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     return TFFT_OK;
 }
 
+// ---------------------------------------------------------------- (f-4) fp64 audit transform
+static int audit_run(tfft_ctx* c, double* host, const uint8_t* rgb, int w, int h, int center, int n_planes, int ph, int pw, int inverse) {
+    const size_t bytes = (size_t)n_planes * ph * pw * sizeof(double2);
+    double2 *a = nullptr, *scratch = nullptr, *wtab = nullptr;
+    uint8_t* img = nullptr;
+    int rc = TFFT_OK;
+    auto done = [&](int r) { (void)hipFree(a); (void)hipFree(scratch); (void)hipFree(wtab); (void)hipFree(img); return r; };
+    if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&scratch, bytes) != hipSuccess ||
+        hipMalloc((void**)&wtab, (size_t)(ph > pw ? ph : pw) * sizeof(double2)) != hipSuccess) return done(TFFT_E_NOMEM);
+    hipError_t e;
+    if (rgb) {
+        const size_t ib = (size_t)w * h * 3;
+        if (hipMalloc((void**)&img, ib) != hipSuccess) return done(TFFT_E_NOMEM);
+        e = hipMemcpyAsync(img, rgb, ib, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = audit_load_rgb8_f64(img, w, h, pw, ph, center, a, c->stream);
+    } else {
+        e = hipMemcpyAsync(a, host, bytes, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = audit_fft2d_f64(a, scratch, wtab, n_planes, ph, pw, inverse, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, a, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { c->last_hip = (int)e; rc = TFFT_E_HIP; }
+    return done(rc);
+}
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int tfft_audit_fft2d_f64(tfft_ctx* c, double* planes, int n_planes, int ph, int pw, int inverse) {
+    if (!c || !planes || n_planes < 1 || !is_pow2(ph) || !is_pow2(pw) || ph > TFFT_MAX_DIM || pw > TFFT_MAX_DIM) return TFFT_E_INVALID;
+    return audit_run(c, planes, nullptr, 0, 0, 0, n_planes, ph, pw, inverse);
+}
+
+int tfft_audit_forward_rgb8_f64(tfft_ctx* c, const uint8_t* rgb, int w, int h, int center, double* out) {
+    if (!c || !rgb || !out || w < 1 || h < 1 || w > TFFT_MAX_DIM || h > TFFT_MAX_DIM) return TFFT_E_INVALID;
+    int pw = 1, ph = 1;
+    while (pw < w) pw <<= 1;
+    while (ph < h) ph <<= 1;
+    return audit_run(c, out, rgb, w, h, center, 3, ph, pw, 0);
+}
+
 int tfft_timer_begin(tfft_ctx* c) {
     if (!c) return TFFT_E_INVALID;
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));

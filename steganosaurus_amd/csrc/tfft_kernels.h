@@ -93,6 +93,9 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
                            hipStream_t s);
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s);
+// (f-4) fp64 audit transform, tfft_audit64.hip
+hipError_t audit_fft2d_f64(double2* a, double2* scratch, double2* wtab, int n_planes, int PH, int PW, int inverse, hipStream_t s);
+hipError_t audit_load_rgb8_f64(const uint8_t* rgb_dev, int W, int H, int PW, int PH, int center, double2* out, hipStream_t s);
 // highest stored row any bin of the list touches -> *last_row (device int, reset here)
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,

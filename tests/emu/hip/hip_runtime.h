@@ -30,6 +30,8 @@ struct float2 { float x, y; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+struct alignas(16) double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}

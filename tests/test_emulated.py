@@ -187,3 +187,8 @@ def test_context_reuse_across_geometries(emu, orc):
 def test_bit_index_address_order(emu, orc):
     PC.check_bit_index(emu, orc, 64, 48, 700)
     PC.check_bit_index(emu, orc, 100, 64, 500, jitter=0.05)
+
+
+def test_audit64_is_the_reference_fft_bit_for_bit(emu, orc):
+    PC.check_audit64_against_oracle(emu, orc, [(64, 64), (48, 40), (100, 30), (16, 1), (1, 8)])
+    PC.check_product_against_audit64(emu, 200, 96)

@@ -350,3 +350,14 @@ def test_bit_index_address_order(lib, orc):
     assert (got != bits).mean() < 1e-3
     PC.check_bit_index(lib, orc, 600, 400, 20000, jitter=0.05)
     PC.check_bit_index(lib, orc, 1920, 1080, 231184)
+
+
+def test_audit64_is_the_reference_fft_bit_for_bit(lib, orc):
+    PC.check_audit64_against_oracle(lib, orc, [(64, 64), (48, 40), (600, 400), (512, 512), (16, 1), (1, 8)])
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080), (3840, 2160), (8192, 8192)])
+def test_fp32_spectrum_against_fp64_audit_at_full_size(lib, wh):
+    """BASELINE configs 2, 3 and 5 at FULL size: every coefficient of the fp32 product spectrum against the
+    reference's own arithmetic (fp64 radix-2, evaluated on the device) -- the CPU oracle needs minutes here."""
+    PC.check_product_against_audit64(lib, wh[0], wh[1], center=(wh[0] == 3840))
