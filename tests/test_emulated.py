@@ -109,7 +109,18 @@ def test_batch_matches_single(emu, orc):
         assert np.array_equal(st, out[i]), i
         one.forward_rgb8(st)
         assert np.array_equal(one.read_bins(bins), raw[i]), i
-    one.close(); ctx.close()
+    one.close()
+    # the same batch with the bins in address order (tfft_bins_sort + tfft_set_bit_index) and, for the
+    # extraction, the row-limited final column step: identical stego bytes, capacities and stream-order bits
+    sbins, idx = B.bins_sort(bins, lib=emu)
+    ctx.set_bit_index(idx)
+    out2 = np.zeros_like(imgs); usable2 = np.zeros(nimg, np.uint64); raw2 = np.zeros((nimg, n), np.uint8)
+    ctx.embed_batch_dev(nimg, imgs.ctypes.data, w, h, sbins.ctypes.data, bits.ctypes.data, n, out2.ctypes.data,
+                        usable_ptr=usable2.ctypes.data)
+    ctx.extract_batch_dev(nimg, out2.ctypes.data, w, h, sbins.ctypes.data, n, raw2.ctypes.data)
+    ctx.sync()
+    assert np.array_equal(out2, out) and np.array_equal(usable2, usable) and np.array_equal(raw2, raw)
+    ctx.close()
 
 
 def test_unaligned_device_pointers(emu):

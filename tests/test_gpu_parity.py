@@ -272,7 +272,35 @@ def test_batch_matches_single(lib, orc):
         assert np.array_equal(st, out[i]), i
         one.forward_rgb8(st)
         assert np.array_equal(one.read_bins(bins), raw[i]), i
-    one.close(); ctx.close()
+    one.close()
+    # bins in address order + bit index (+ the row-limited extraction forward), and the two-stream split:
+    # identical stego bytes, capacities and stream-order bits
+    sbins, idx = B.bins_sort(bins, lib=lib)
+    d_sb = torch.from_numpy(sbins.view(np.uint8).reshape(-1, 8).copy()).to(dev)
+    ctx.set_bit_index(idx)
+    d_out2 = torch.zeros_like(d_img); d_us2 = torch.zeros_like(d_usable); d_raw2 = torch.zeros_like(d_raw)
+    ctx.embed_batch_dev(nimg, d_img.data_ptr(), w, h, d_sb.data_ptr(), d_bits.data_ptr(), n, d_out2.data_ptr(),
+                        usable_ptr=d_us2.data_ptr())
+    ctx.extract_batch_dev(nimg, d_out2.data_ptr(), w, h, d_sb.data_ptr(), n, d_raw2.data_ptr())
+    ctx.sync()
+    assert np.array_equal(d_out2.cpu().numpy(), out) and np.array_equal(d_us2.cpu().numpy(), usable)
+    assert np.array_equal(d_raw2.cpu().numpy(), raw)
+    ctx.close()
+    os.environ["TFFT_STREAMS"] = "2"
+    try:
+        c2 = B.Context(w, h, slots=8, lib=lib)
+    finally:
+        del os.environ["TFFT_STREAMS"]
+    imgs8 = np.concatenate([imgs, imgs[:3]]); bits8 = np.concatenate([bits, bits[:3]])
+    d_i8 = torch.from_numpy(imgs8).to(dev); d_b8 = torch.from_numpy(bits8).to(dev)
+    d_o8 = torch.zeros_like(d_i8); d_r8 = torch.zeros((8, n), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    c2.embed_batch_dev(8, d_i8.data_ptr(), w, h, d_bins.data_ptr(), d_b8.data_ptr(), n, d_o8.data_ptr())
+    c2.extract_batch_dev(8, d_o8.data_ptr(), w, h, d_bins.data_ptr(), n, d_r8.data_ptr())
+    c2.sync()
+    assert np.array_equal(d_o8.cpu().numpy()[:5], out) and np.array_equal(d_r8.cpu().numpy()[:5], raw)
+    assert np.array_equal(d_o8.cpu().numpy()[5:], out[:3])
+    c2.close()
 
 
 def test_host_batch_pipeline(lib, orc):
