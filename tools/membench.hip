@@ -17,6 +17,28 @@ __global__ void k_copy(const float4* __restrict__ in, float4* __restrict__ out, 
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// copy variants: U independent 16-byte loads in flight per thread, optional non-temporal loads / stores
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int U, bool NTL, bool NTS>
+__global__ void k_copy_v(const float4* __restrict__ in4, float4* __restrict__ out4, size_t n) {
+    const v4f* in = reinterpret_cast<const v4f*>(in4);
+    v4f* out = reinterpret_cast<v4f*>(out4);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride * U) {
+        v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t j = i + u * stride;
+            if (j < n) v[u] = NTL ? __builtin_nontemporal_load(in + j) : in[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t j = i + u * stride;
+            if (j < n) { if (NTS) __builtin_nontemporal_store(v[u], out + j); else out[j] = v[u]; }
+        }
+    }
+}
+
 // read-only stream (the shape of the median / capacity passes): U independent 16-byte loads per thread per
 // iteration, grid-stride; the sum keeps the loads alive
 template <int U>
@@ -74,6 +96,28 @@ int main() {
         for (int i = 0; i < 5; i++) k_copy<<<2048, 256>>>((const float4*)a, (float4*)b, big / 16);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         if (rep) printf("copy 1.5 GiB          : %7.1f GB/s\n", 5 * 2.0 * big / time_ms(e0, e1) / 1e6);
+    }
+    {
+        const int grids[] = {1024, 2048, 4096, 8192};
+        for (int g : grids) {
+            float r[6];
+            for (int v = 0; v < 6; v++) {
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 5; i++) {
+                        if (v == 0) k_copy_v<1, false, false><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                        if (v == 1) k_copy_v<4, false, false><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                        if (v == 2) k_copy_v<4, false, true><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                        if (v == 3) k_copy_v<4, true, true><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                        if (v == 4) k_copy_v<8, false, true><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                        if (v == 5) k_copy_v<1, false, true><<<g, 256>>>((const float4*)a, (float4*)b, big / 16);
+                    }
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    r[v] = 5 * 2.0 * big / time_ms(e0, e1) / 1e6;
+                }
+            }
+            printf("copy 1.5 GiB grid %5d x256: u1 %7.1f  u4 %7.1f  u4+nt-store %7.1f  u4+nt-both %7.1f  u8+nt-store %7.1f  u1+nt-store %7.1f GB/s\n", g, r[0], r[1], r[2], r[3], r[4], r[5]);
+        }
     }
     {
         float* sink; CK(hipMalloc(&sink, 4));
