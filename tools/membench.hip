@@ -39,6 +39,12 @@ __global__ void k_copy_v(const float4* __restrict__ in4, float4* __restrict__ ou
     }
 }
 
+// write-only stream (the shape of the fused forward kernel's output: 8 bytes written per 1 read)
+__global__ void k_write(float4* __restrict__ out, size_t n, float v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = make_float4(v, v, v, v);
+}
+
 // read-only stream (the shape of the median / capacity passes): U independent 16-byte loads per thread per
 // iteration, grid-stride; the sum keeps the loads alive
 template <int U>
@@ -118,6 +124,16 @@ int main() {
             }
             printf("copy 1.5 GiB grid %5d x256: u1 %7.1f  u4 %7.1f  u4+nt-store %7.1f  u4+nt-both %7.1f  u8+nt-store %7.1f  u1+nt-store %7.1f GB/s\n", g, r[0], r[1], r[2], r[3], r[4], r[5]);
         }
+    }
+    for (int g : {1024, 2048, 4096, 8192}) {
+        float r = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 5; i++) k_write<<<g, 256>>>((float4*)b, big / 16, (float)i);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            r = 5.0 * big / time_ms(e0, e1) / 1e6;
+        }
+        printf("write-only 1.5 GiB grid %5d x256: %7.1f GB/s\n", g, r);
     }
     {
         float* sink; CK(hipMalloc(&sink, 4));
