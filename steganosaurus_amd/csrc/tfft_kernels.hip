@@ -194,6 +194,20 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
     }
 }
 
+// XCD-aware workgroup order for the kernels whose three colour-plane workgroups share cache lines (the
+// interleaved u8 rows).  Workgroups go to the 8 XCDs round robin by linear id and every XCD has its own L2,
+// so the three planes of one row group are given ids 8 apart: same XCD, dispatched back to back.  With the
+// natural (n2, plane, image) grid they were 256 ids apart -- same XCD but ~2 MB of other traffic later --
+// and the u8 lines were written back partially three times (WRITE_SIZE 2.7x the image bytes).
+//   grid.x = N2 * 3 (N2 a multiple of 8, else the natural order is kept), grid.y = images
+__device__ __forceinline__ void xcd_plane_order(int N2, int& n2, int& plane) {
+    const int L = blockIdx.x;
+    if (N2 & 7) { n2 = L % N2; plane = L / N2; return; }
+    const int xcd = L & 7, q = L >> 3;
+    plane = q % 3;
+    n2 = (q / 3) * 8 + xcd;
+}
+
 // ---------------------------------------------------------------------------
 // rows + first column step, fused (images up to 2048 wide, PH = N1*N2 with N1 = 8):
 // a workgroup holds the N1 rows y = n1*N2 + n2 of one plane in LDS, one wave per row.
@@ -202,7 +216,7 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
 // column, multiplies by w^(n2*k1) and stores rows k1*N2 + n2: the result is what
 // k_rows_fwd followed by the first k_fft_cols step leaves in `out`, without writing
 // and re-reading the H x M intermediate.
-//   grid (N2, 3, n_images)   block (64, N1)   M = 1024, E = 16
+//   grid (3*N2, n_images) in xcd_plane_order   block (64, N1)   M = 1024, E = 16
 // ---------------------------------------------------------------------------
 template <int LOGN1>
 __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out,
@@ -210,7 +224,9 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
     const int t = threadIdx.x, n1 = threadIdx.y;
     const int N2 = P.PH >> LOGN1;
-    const int n2 = blockIdx.x, plane = blockIdx.y, img = blockIdx.z;
+    int n2, plane;
+    xcd_plane_order(N2, n2, plane);
+    const int img = blockIdx.y;
     const int y = n1 * N2 + n2;
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
@@ -341,7 +357,7 @@ __device__ __forceinline__ unsigned quantise_u8(float v) {
 // n1*N2 + n2 in LDS; one wave per row then does the half-spectrum -> real row
 // transform, scales, rounds and stores its plane's bytes.  Rows >= H are dropped.
 // Replaces the second k_fft_cols inverse step followed by k_rows_inv.
-//   grid (N2, 3, n_images)   block (64, N1)   M = 1024, E = 16
+//   grid (3*N2, n_images) in xcd_plane_order   block (64, N1)   M = 1024, E = 16
 // ---------------------------------------------------------------------------
 template <int LOGN1>
 // (140 VGPRs leave one workgroup of 8 waves per CU; forcing 128 with amdgpu_waves_per_eu(4) spills 19 dwords and
@@ -351,7 +367,9 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
     constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
     const int t = threadIdx.x, n1 = threadIdx.y;
     const int N2 = P.PH >> LOGN1;
-    const int n2 = blockIdx.x, plane = blockIdx.y, img = blockIdx.z;
+    int n2, plane;
+    xcd_plane_order(N2, n2, plane);
+    const int img = blockIdx.y;
     const int y = n1 * N2 + n2;
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
@@ -365,12 +383,12 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
 #pragma unroll
     for (int i = 0; i < NT; i++) tv[i] = tw[2 * (n1 * T + t + i * T * N1)];
 
-    // split twiddles exp(+2 pi i k/PW) of this lane's bins, fetched ahead of the column phase: the kernel sits
-    // at one workgroup per CU either way (140..168 VGPRs), so the 32 registers are free
-    float2 wsp[E];
+    // split twiddles exp(+2 pi i k/PW), k = t + 64 j <= M/2, fetched ahead of the column phase
+    constexpr int NSPLIT = (M / 2) / T + 1;
+    float2 wsp[NSPLIT];
     if (y < P.H) {
 #pragma unroll
-        for (int m = 0; m < E; m++) wsp[m] = tw[t + m * T];
+        for (int j = 0; j < NSPLIT; j++) wsp[j] = tw[imin(t + j * T, M / 2)];
     }
 
     // ---- length-N1 inverse DFT across the rows, per column
@@ -388,22 +406,29 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
     __syncthreads();
     if (y >= P.H) return;               // wave uniform (one wave per row); no barrier follows
 
-    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
-    // branch-free, the packed bin k == 0 (lane 0, m == 0) included: as a divergent branch its twiddle load
-    // was followed by s_waitcnt vmcnt(0) -- one full memory round trip before the other 15 loads were issued
+    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k, done IN PLACE
+    // in LDS one pair (k, M-k) at a time: Ev[M-k] = conj Ev[k] and Od[M-k] = conj Od[k] (w^M = -1), so the pair
+    // shares its loads, its twiddle and half its arithmetic.  Building all 16 of a thread's Z in registers
+    // instead kept 48 loads in flight and the kernel at 146 VGPRs, i.e. ONE workgroup per CU.
+#pragma unroll
+    for (int j = 0; j < NSPLIT; j++) {
+        const int k = t + j * T;
+        if (k <= M / 2) {
+            const int k2 = (M - k) & (M - 1);
+            const float2 xk = lds[lay.idx(k, n1)], xm = lds[lay.idx(k2, n1)];
+            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 od = cmul(d, cconj(wsp[j]));
+            float2 zk = make_float2(ev.x - od.y, ev.y + od.x);
+            if (k == 0) zk = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));     // X[0], X[M] packed in bin 0
+            lds[lay.idx(k, n1)] = zk;
+            if (k2 != k) lds[lay.idx(k2, n1)] = make_float2(ev.x + od.y, od.x - ev.y);
+        }
+    }
+    WaveSync::sync();
     float2 u[E];
 #pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int k = t + m * T;
-        const float2 xk = lds[lay.idx(k, n1)];
-        const float2 xm = lds[lay.idx((M - k) & (M - 1), n1)];
-        const float2 w = wsp[m];
-        const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-        const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-        const float2 od = cmul(d, cconj(w));
-        u[m] = make_float2(ev.x - od.y, ev.y + od.x);
-        if (m == 0 && k == 0) u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));   // X[0], X[M] packed in bin 0
-    }
+    for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
     WaveSync::sync();
     fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
 #pragma unroll
@@ -1234,7 +1259,7 @@ hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_p
     auto k = k_rowcol_fwd<LOGN1>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(P.PH >> LOGN1, 3, n_images), dim3(64, 1 << LOGN1), lds, s, rgb, out, tw_pw, tw_ph, P);
+    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(64, 1 << LOGN1), lds, s, rgb, out, tw_pw, tw_ph, P);
     return hipGetLastError();
 }
 hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
@@ -1243,7 +1268,7 @@ hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw
     auto k = k_colrow_inv<LOGN1>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(P.PH >> LOGN1, 3, n_images), dim3(64, 1 << LOGN1), lds, s, in, rgb, tw_pw, P);
+    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(64, 1 << LOGN1), lds, s, in, rgb, tw_pw, P);
     return hipGetLastError();
 }
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
