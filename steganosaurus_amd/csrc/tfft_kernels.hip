@@ -481,29 +481,35 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
     constexpr bool LAZY = LOGM >= TFFT_ROWS_LAZY_LOG;      // see k_rows_fwd
     float2 W[LAZY ? 1 : tw_regs<M, E>()];
     if (!LAZY) fft_prefetch_twiddles<M, E, -1>(W, t, tw, 2);
-    float2 wk[E];
+    constexpr int NSPLIT = (M / 2) / T + 1;
+    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW), k = t + j*T <= M/2
 #pragma unroll
-    for (int m = 0; m < E; m++) wk[m] = tw[t + m * T];
+    for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = xin[m];
     Sync::sync();
 
-    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k
-    float2 u[E];
+    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k, in place in LDS
+    // one pair (k, M-k) at a time (Ev[M-k] = conj Ev[k], Od[M-k] = conj Od[k]; see k_colrow_inv)
 #pragma unroll
-    for (int m = 0; m < E; m++) {
-        const int k = t + m * T;
-        const float2 xk = xin[m];
-        if (k == 0) {
-            u[m] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));
-        } else {
-            const float2 xm = lds[lay.idx(M - k, pb)];
+    for (int j = 0; j < NSPLIT; j++) {
+        const int k = t + j * T;
+        if (k <= M / 2) {
+            const int k2 = (M - k) & (M - 1);
+            const float2 xk = lds[lay.idx(k, pb)], xm = lds[lay.idx(k2, pb)];
             const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
             const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(wk[m]));
-            u[m] = make_float2(ev.x - od.y, ev.y + od.x);
+            const float2 od = cmul(d, cconj(wk[j]));
+            float2 zk = make_float2(ev.x - od.y, ev.y + od.x);
+            if (k == 0) zk = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));     // X[0], X[M] packed in bin 0
+            lds[lay.idx(k, pb)] = zk;
+            if (k2 != k) lds[lay.idx(k2, pb)] = make_float2(ev.x + od.y, od.x - ev.y);
         }
     }
+    Sync::sync();
+    float2 u[E];
+#pragma unroll
+    for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, pb)];
     Sync::sync();
     if (LAZY) fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, pb, tw, 2);
     else fft_block<M, E, -1, Sync>(u, lds, lay, t, pb, W);
