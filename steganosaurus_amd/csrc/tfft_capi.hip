@@ -60,6 +60,7 @@ struct tfft_ctx {
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_streams = 1;
+    int n_cus = 0, collect_resident = 0;  // grid sizing of the full median pass: fill every CU to the same depth
     const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
     uint32_t* bit_index = nullptr;        // tfft_set_bit_index: bins[i] carries stream bit bit_index[i]
     uint64_t bit_index_n = 0;
@@ -265,7 +266,7 @@ CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax)
 int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st) {
     const Slot& s = c->slots[s0];
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
-                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, st));
+                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st));
     return TFFT_OK;
 }
 
@@ -333,6 +334,8 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->device = device; c->max_w = max_w; c->max_h = max_h; c->n_slots = n_slots;
     if (const char* e = getenv("TFFT_COLS_DIRECT_MAX_LOG")) c->cols_direct_max_log = atoi(e);
     if (const char* e = getenv("TFFT_COLS_LOG_N1")) c->cols_force_log_n1 = atoi(e);
+    c->n_cus = prop.multiProcessorCount;
+    c->collect_resident = collect_bracket_resident_blocks();
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);

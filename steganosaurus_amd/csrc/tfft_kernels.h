@@ -103,7 +103,8 @@ hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits,
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
                        int n_images, uint8_t* bits_out, int* err, hipStream_t s);
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
-                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, hipStream_t s);
+                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident, hipStream_t s);
+int collect_bracket_resident_blocks();
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s);
 hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,

@@ -1350,7 +1350,8 @@ static unsigned stat_blocks(int rows, int n_images) {
 }
 
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
-                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, hipStream_t s) {
+                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident,
+                          hipStream_t s) {
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
     const unsigned nb = stat_blocks(PH, n_images);
@@ -1366,15 +1367,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
         // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
         // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
-        static int resident = 0, cus = 0;
-        if (!resident) {
-            int dev = 0, r = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_collect_bracket, 256, (1024 + 4 * 512 + 8) * sizeof(unsigned)) != hipSuccess) r = 0;
-            resident = r > 0 ? r : 4;
-            if (cus <= 0) cus = 256;
-        }
+        const int cus = fill_cus > 0 ? fill_cus : 256, resident = fill_resident > 0 ? fill_resident : 4;
         unsigned nbc = (unsigned)(((long long)cus * resident) / (3LL * n_images));
         if (nbc > (unsigned)((PH + 3) / 4)) nbc = (unsigned)((PH + 3) / 4);
         if (nbc > TFFT_STAT_MAX_BLOCKS) nbc = TFFT_STAT_MAX_BLOCKS;
@@ -1393,6 +1386,13 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     hipLaunchKernelGGL(k_hist_cand<false>, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
     hipLaunchKernelGGL(k_select<3>, gs, dim3(256), sel_lds, s, st, med_out);
     return hipGetLastError();
+}
+
+// workgroups of k_collect_bracket that one CU holds at a time (queried once per context)
+int collect_bracket_resident_blocks() {
+    int r = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_collect_bracket, 256, (1024 + 4 * 512 + 8) * sizeof(unsigned)) != hipSuccess) r = 0;
+    return r;
 }
 
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
