@@ -41,6 +41,21 @@ extern __shared__ __attribute__((aligned(16))) unsigned char tfft_smem[];
 // that medians, capacity and embed agree bit for bit)
 __device__ __forceinline__ float mag_of(float2 v) { return sqrtf(fmaf(v.x, v.x, v.y * v.y)); }
 
+// XCD-aware workgroup order for the kernels whose three colour-plane workgroups share cache lines (the
+// interleaved u8 rows).  Workgroups go to the 8 XCDs round robin by linear id and every XCD has its own L2,
+// so the three planes of one row group are given ids 8 apart: same XCD, dispatched back to back.  With the
+// natural (n2, plane, image) grid they were 256 ids apart -- same XCD but ~2 MB of other traffic later --
+// and the u8 lines were written back partially three times (WRITE_SIZE 2.7x the image bytes).
+//   grid.x = N2 * 3 (N2 a multiple of 8, else the natural order is kept), grid.y or .z = images
+// Used by the fused kernels (N2 row groups) and by the one-plane-per-workgroup row kernels (N2 = H rows).
+__device__ __forceinline__ void xcd_plane_order(int N2, int& n2, int& plane) {
+    const int L = blockIdx.x;
+    if (N2 & 7) { n2 = L % N2; plane = L / N2; return; }
+    const int xcd = L & 7, q = L >> 3;
+    plane = q % 3;
+    n2 = (q / 3) * 8 + xcd;
+}
+
 // The four samples of colour plane p (0..2) in one 12-byte group of four RGB pixels a|b|c: bytes p, p+3,
 // p+6, p+9.  Two byte-aligned 32-bit windows hold them at byte 0 and byte 3 (v_alignbyte_b32 takes its
 // shift modulo 4, hence the select for p == 2), and byte -> float is one v_cvt_f32_ubyteN each: ~10
@@ -68,8 +83,9 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
-    const int y = blockIdx.x, img = blockIdx.z;
-    const int plane0 = blockIdx.y * PPB;
+    int y = blockIdx.x, plane0 = blockIdx.y * PPB;
+    if (PPB == 1) xcd_plane_order(P.H, y, plane0);      // grid.x = 3*H: the three planes of a row on one XCD, back to back
+    const int img = blockIdx.z;
     const int tid = pb * T + t, nthr = T * PPB;
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
@@ -192,20 +208,6 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
             if (k2 != k) dst[k2] = cconj(csub(a, b));
         }
     }
-}
-
-// XCD-aware workgroup order for the kernels whose three colour-plane workgroups share cache lines (the
-// interleaved u8 rows).  Workgroups go to the 8 XCDs round robin by linear id and every XCD has its own L2,
-// so the three planes of one row group are given ids 8 apart: same XCD, dispatched back to back.  With the
-// natural (n2, plane, image) grid they were 256 ids apart -- same XCD but ~2 MB of other traffic later --
-// and the u8 lines were written back partially three times (WRITE_SIZE 2.7x the image bytes).
-//   grid.x = N2 * 3 (N2 a multiple of 8, else the natural order is kept), grid.y = images
-__device__ __forceinline__ void xcd_plane_order(int N2, int& n2, int& plane) {
-    const int L = blockIdx.x;
-    if (N2 & 7) { n2 = L % N2; plane = L / N2; return; }
-    const int xcd = L & 7, q = L >> 3;
-    plane = q % 3;
-    n2 = (q / 3) * 8 + xcd;
 }
 
 // ---------------------------------------------------------------------------
@@ -466,8 +468,9 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
                            RowParams P) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
-    const int y = blockIdx.x, img = blockIdx.z;
-    const int plane0 = blockIdx.y * PPB;
+    int y = blockIdx.x, plane0 = blockIdx.y * PPB;
+    if (PPB == 1) xcd_plane_order(P.H, y, plane0);      // grid.x = 3*H: the three planes of a row on one XCD, back to back
+    const int img = blockIdx.z;
     const int tid = pb * T + t, nthr = T * PPB;
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
@@ -1231,7 +1234,7 @@ static hipError_t launch_rows_t(const void* in, void* out, const float2* tw, con
                                 hipStream_t s) {
     constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
     const size_t lds = (size_t)PPB * LayRows::padded(M) * sizeof(float2);
-    dim3 grid(P.H, 3 / PPB, n_images), block(T, PPB, 1);
+    dim3 grid(PPB == 1 ? P.H * 3 : P.H, PPB == 1 ? 1 : 3 / PPB, n_images), block(T, PPB, 1);
     if (FWD) {
         auto k = k_rows_fwd<LOGM, PPB>;
         if (lds > 48 * 1024) {

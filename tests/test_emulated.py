@@ -40,6 +40,9 @@ def test_forward_wide_rows_wave_sync_path(emu, orc):
     # PW = 4096 -> M = 2048: one plane per workgroup (two waves), own fast staging path; 2101 is not a multiple of 4
     PC.check_forward_against_oracle(emu, orc, [(2100, 2), (2101, 2)], centers=(0, 1))
     PC.check_identity_roundtrip(emu, [(2100, 3), (2101, 2)])
+    # H a multiple of 8: the XCD-aware (row, plane) workgroup order of the one-plane kernels
+    PC.check_forward_against_oracle(emu, orc, [(2100, 8)], centers=(1,))
+    PC.check_identity_roundtrip(emu, [(2104, 16)])
 
 
 def test_median_fast_and_fallback_paths(emu, orc):
