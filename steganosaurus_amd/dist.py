@@ -19,12 +19,15 @@ def shard(n_total: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_bins(bins_u8: torch.Tensor, src: int = 0) -> torch.Tensor:
-    """Broadcast the (n_bits, 8) uint8 view of the tfft_bin list computed on `src` (8 B x n_bits)."""
+def broadcast_bins(bins_u8: torch.Tensor, src: int = 0, bit_index: torch.Tensor = None):
+    """Broadcast the (n_bits, 8) uint8 view of the tfft_bin list computed on `src` (8 B x n_bits) and, when the
+    list was put in address order (tfft_bins_sort), the int64 bit index that goes with it (tfft_set_bit_index)."""
     _, ws = world()
     if ws > 1:
         dist.broadcast(bins_u8, src=src)
-    return bins_u8
+        if bit_index is not None:
+            dist.broadcast(bit_index, src=src)
+    return bins_u8 if bit_index is None else (bins_u8, bit_index)
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

@@ -309,15 +309,19 @@ def _rank_main(rank, world, port, tmpdir, kat_key_walk):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_bits = 5000
     bins = torch.zeros((n_bits, 8), dtype=torch.uint8)
+    index = torch.zeros(n_bits, dtype=torch.int64)
     if rank == 0:
         wk = B.Walk(bytes.fromhex(kat_key_walk), 256, 256)
-        bins.copy_(torch.from_numpy(wk.next(n_bits).view(np.uint8).reshape(-1, 8).copy()))
-    D.broadcast_bins(bins, 0)
+        sb, idx = B.bins_sort(wk.next(n_bits))              # address order + the bit index that goes with it
+        bins.copy_(torch.from_numpy(sb.view(np.uint8).reshape(-1, 8).copy()))
+        index.copy_(torch.from_numpy(idx.astype(np.int64)))
+    D.broadcast_bins(bins, 0, bit_index=index)
+    assert sorted(index.tolist()) == list(range(n_bits))
     lo, hi = D.shard(7, rank, world)
     raw = torch.full((4, 16), rank, dtype=torch.uint8)
     got = D.gather_bits(raw, 0)
     t = D.max_over_ranks(1.0 + rank)
-    np.save(os.path.join(tmpdir, "r%d.npy" % rank), np.array([hashlib.sha256(bins.numpy().tobytes()).hexdigest(), lo, hi, t,
+    np.save(os.path.join(tmpdir, "r%d.npy" % rank), np.array([hashlib.sha256(bins.numpy().tobytes() + index.numpy().tobytes()).hexdigest(), lo, hi, t,
                                                               -1 if got is None else len(got)], dtype=object), allow_pickle=True)
     dist.destroy_process_group()
 
