@@ -91,8 +91,9 @@ def kernel_bytes(stage, w, h, n_bits, two_step, read_rows_frac=1.0):
         "read": n_bits * (8 + 8 + 1),
         "medians": 3 * 3 * plane_full,
         "capacity": 0,
-        # final forward column step of the extract path: reads everything, stores the rows the bin list touches
-        "cols_fwd_read": int(3 * plane_full + 3 * plane_full * read_rows_frac),
+        # final forward column step of the extract path: reads everything and takes the bits out of its LDS-resident
+        # tiles (no spectrum store; TFFT_TILE_READ=0: stores the rows the bin list touches, then k_read)
+        "cols_fwd_read": int(3 * plane_full + (n_bits * (8 + 1) if read_rows_frac is None else 3 * plane_full * read_rows_frac)),
     }[stage]
 
 
@@ -116,7 +117,7 @@ def algorithmic_bytes(stage, w, h, n_bits, two_step):
         "cols_inv_b": 0 if fused else (col // 2 if split else 0),
         "embed": 40 * n_bits, "read": 16 * n_bits,
         "medians": 0, "capacity": 0,        # not in the 8(d) model: their time counts against the path fraction only
-        "cols_fwd_read": col if fused else (col // 2 if split else col),      # the final forward column step, extraction's variant
+        "cols_fwd_read": (col if fused else (col // 2 if split else col)) + 16 * n_bits,      # extraction's final forward column step (+ the gather it absorbs)
     }[stage]
 
 
@@ -321,7 +322,7 @@ def main():
         order = [0, 1, 2, 10, "clean", 8, 9, 3, 7, 4, 5, 6]
         hb = bins if rank == 0 else None
         last_row = int(np.where(hb["x"] <= PW // 2, hb["y"], (PH - hb["y"].astype(np.int64)) % PH).max())
-        rows_frac = (last_row + 1) / PH
+        rows_frac = None if os.environ.get("TFFT_TILE_READ", "1") != "0" else (last_row + 1) / PH
         for sid in order:
             if sid == "clean":
                 for k in (0, 1, 2):

@@ -57,6 +57,10 @@ struct tfft_ctx {
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
+    // spectrum-free extraction (k_fft_cols<..., COLS_READ>): the bin list bucketed by column tile, per compute stream
+    struct TileBuckets { unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0; } tb[2];
+    const ColParams* fwd_read = nullptr;  // when set, the final forward column step runs in COLS_READ mode with these rd_* fields
+    int tile_read = 1;                    // TFFT_TILE_READ=0: row-limited spectrum + k_read always; 1: tile read for chunks of >= 8 images; 3: always; 2: always, with the global-atomic bucket build
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_streams = 1;
@@ -174,6 +178,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
                 cp.last_row_dev = c->fwd_last_row;
+                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; }
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
@@ -185,6 +190,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             // for every k1: length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
             cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
             cp.last_row_dev = c->fwd_last_row;
+            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; }
             HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
@@ -338,6 +344,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->collect_resident = collect_bracket_resident_blocks();
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
+    if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
@@ -373,6 +380,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipDeviceSynchronize();
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
+    for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
     (void)hipFree(c->out_pool);
@@ -617,20 +625,66 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
     HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
     return enqueue_inverse(c, s0, g, rgb_out, st);
 }
+// device buffers of the tile buckets for `n` bins and `nb` buckets on compute stream `which`
+static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
+    auto& b = c->tb[which];
+    if (n > b.cap || !b.ent) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        (void)hipFree(b.ent); b.ent = nullptr; b.cap = 0;
+        const uint64_t cap = n + n / 4 + 1024;
+        if (dev_alloc(c, (void**)&b.ent, cap * sizeof(TileBin))) return TFFT_E_NOMEM;
+        b.cap = cap;
+    }
+    if (nb + 1 > b.nb_cap || !b.cnt) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        (void)hipFree(b.cnt); (void)hipFree(b.off); b.cnt = b.off = nullptr; b.nb_cap = 0;
+        if (dev_alloc(c, (void**)&b.cnt, (size_t)(nb + 1) * sizeof(unsigned)) || dev_alloc(c, (void**)&b.off, (size_t)(nb + 1 + (nb + 1023) / 1024) * sizeof(unsigned)))
+            return TFFT_E_NOMEM;
+        b.nb_cap = nb + 1;
+    }
+    if (!b.ep && dev_alloc(c, (void**)&b.ep, sizeof(EmbedParams))) return TFFT_E_NOMEM;
+    return TFFT_OK;
+}
+
 static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, uint64_t n_bits,
                          double alpha, uint8_t* bits_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
-    // the spectrum is only read at the bins of the list: rows above the highest one are never stored
-    int* last_row = c->last_row + ((c->stream2 && st == c->stream2) ? 1 : 0);
-    HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
-    c->fwd_last_row = last_row;
-    int rc = enqueue_forward(c, s0, g, rgb_in, st);
-    c->fwd_last_row = nullptr;
-    if (rc) return rc;
+    const int which = (c->stream2 && st == c->stream2) ? 1 : 0;
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
-    HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
-    for (int i = 0; i < g; i++) c->slots[s0 + i].has_spec = false;      // partial spectrum: not for tfft_medians & co
+    int rc;
+    // (the bucket build is per call: it pays off from about 8 images per chunk; TFFT_TILE_READ=2/3 force it)
+    if (c->tile_read && n_bits > 0 && (g >= 8 || c->tile_read >= 2)) {
+        // The spectrum is only ever read at the bins of the list: bucket them by column tile and let the final
+        // forward column step read the bits out of its LDS-resident tiles -- no spectrum store, no k_read.
+        const ColPlan pl = plan_cols(c, s.PH, s.PWi);
+        const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16, nb = 3 * ntiles * G;
+        rc = ensure_buckets(c, which, n_bits, nb);
+        if (rc) return rc;
+        auto& tb = c->tb[which];
+        HIPCHK(c, hipMemsetAsync(bits_out, 0, (size_t)g * n_bits, st));          // bins the walk would never produce read as 0 (k_read does the same)
+        HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
+        ColParams rd{};
+        rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.rd_jitter = nullptr;
+        rd.rd_generic = ep.generic; rd.rd_ep = tb.ep;
+        if (ep.generic) { tb.ep_host = ep; HIPCHK(c, hipMemcpyAsync(tb.ep, &tb.ep_host, sizeof ep, hipMemcpyHostToDevice, st)); }
+        c->fwd_read = &rd;
+        rc = enqueue_forward(c, s0, g, rgb_in, st);
+        c->fwd_read = nullptr;
+        if (rc) return rc;
+    } else {
+        // the spectrum is only read at the bins of the list: rows above the highest one are never stored
+        int* last_row = c->last_row + which;
+        HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
+        c->fwd_last_row = last_row;
+        rc = enqueue_forward(c, s0, g, rgb_in, st);
+        c->fwd_last_row = nullptr;
+        if (rc) return rc;
+        HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
+    }
+    for (int i = 0; i < g; i++) c->slots[s0 + i].has_spec = false;      // partial or no spectrum: not for tfft_medians & co
     return TFFT_OK;
 }
 
@@ -821,18 +875,28 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     *ms_per_rep = 0.f;
     if (launches == 0) return TFFT_OK;
     { const float2* t; int rc = get_twiddles(c, s.PWi, &t); if (rc) return rc; rc = get_twiddles(c, s.PH, &t); if (rc) return rc; }
+    ColParams rd{};
     if (stage == COLS_FWD_READ) {
-        if (!bins_dev) return TFFT_E_INVALID;
-        HIPCHK(c, launch_bins_last_row((const tfft_bin*)bins_dev, n_bits, s.PH, s.PWi, c->last_row, c->stream));
+        if (!bins_dev || !index_ok(c, n_bits)) return TFFT_E_INVALID;
+        if (c->tile_read && n_bits > 0 && (n_images >= 8 || c->tile_read >= 2)) {
+            if (!bits_out_dev) return TFFT_E_INVALID;
+            const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16;
+            int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G);
+            if (rc) return rc;
+            HIPCHK(c, launch_bucket_bins((const tfft_bin*)bins_dev, c->bit_index, n_bits, s.PH, s.PWi, G, c->tb[0].cnt, c->tb[0].off, c->tb[0].ent, c->err, c->tile_read == 2, c->stream));
+            rd.rd_bins = c->tb[0].ent; rd.rd_off = c->tb[0].off; rd.rd_bits = (uint8_t*)bits_out_dev; rd.rd_n = n_bits; rd.rd_ep = c->tb[0].ep;
+        } else {
+            HIPCHK(c, launch_bins_last_row((const tfft_bin*)bins_dev, n_bits, s.PH, s.PWi, c->last_row, c->stream));
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {
         int rc = TFFT_OK;
         switch (stage) {
             case COLS_FWD_READ:
-                c->fwd_last_row = c->last_row;
+                if (rd.rd_bins) c->fwd_read = &rd; else c->fwd_last_row = c->last_row;
                 rc = enqueue_fft_stage(c, 0, n_images, final_fwd, nullptr, nullptr, c->stream);
-                c->fwd_last_row = nullptr;
+                c->fwd_read = nullptr; c->fwd_last_row = nullptr;
                 break;
             case EMBED: {
                 if (!index_ok(c, n_bits)) return TFFT_E_STATE;

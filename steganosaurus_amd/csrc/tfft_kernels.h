@@ -17,6 +17,9 @@ struct RowParams {
     size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
 };
 
+// a bin of the list, located inside its column tile: value at LDS row `k` (= y / G), column `c` (= x % 16)
+struct TileBin { uint16_t k; uint8_t c; uint8_t conj; uint32_t bit; };
+
 struct ColParams {
     int M;             // columns of the half spectrum (PW/2)
     int PH;            // full column length (twiddle table size)
@@ -25,6 +28,14 @@ struct ColParams {
     int out_a, out_b;  // output row = out_a*k + out_b*g
     int in_rows;       // input rows >= in_rows are zero (not loaded)
     int out_rows;      // output rows >= out_rows are not stored
+    // extraction straight out of the tiles (k_fft_cols<..., COLS_READ>): the spectrum is never stored
+    const struct TileBin* rd_bins;   // bins bucketed by (plane, 16-column tile, group g), see k_bucket_*
+    const unsigned* rd_off;          // bucket b = (plane*G + g)*ntiles + tile holds rd_bins[rd_off[b] .. rd_off[b+1])
+    uint8_t* rd_bits;                // bits_out, image i at rd_bits + i*rd_n
+    uint64_t rd_n;
+    const float* rd_jitter;          // per stream bit, or nullptr
+    const struct EmbedParams* rd_ep; // device copy of the read parameters (generic path only dereferences it)
+    int rd_generic;
     const int* last_row_dev;   // optional device scalar: rows > *last_row_dev are not stored either (extraction reads
                                // only the rows its bin list touches; k_bins_last_row)
     int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)
@@ -96,6 +107,9 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
 // (f-4) fp64 audit transform, tfft_audit64.hip
 hipError_t audit_fft2d_f64(double2* a, double2* scratch, double2* wtab, int n_planes, int PH, int PW, int inverse, hipStream_t s);
 hipError_t audit_load_rgb8_f64(const uint8_t* rgb_dev, int W, int H, int PW, int PH, int center, double2* out, hipStream_t s);
+// bucket the bin list by (plane, 16-column tile, row group y % G) for the tile-resident read: counts -> offsets -> entries
+hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, uint64_t n, int PH, int PW, int G,
+                              unsigned* cnt, unsigned* off, TileBin* out, int* err, int force_global, hipStream_t s);
 // highest stored row any bin of the list touches -> *last_row (device int, reset here)
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,

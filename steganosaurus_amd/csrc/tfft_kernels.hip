@@ -572,9 +572,15 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
 //   grid (ceil(M/16), ceil(G/GPB), n_planes)   block (16, T, GPB)
 // ---------------------------------------------------------------------------
 constexpr int cols_threads(int logl) { return imax(256, 16 * ((1 << logl) / elems_for(1 << logl))); }
-// ROWLIMIT: the extraction variant, rows above *P.last_row_dev are not stored (its own symbol, so that a
-// kernel trace tells the two apart)
-template <int LOGL, int SIGN, bool ROWLIMIT = false>
+__device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, int p, const float* __restrict__ jitter, uint64_t j);   // defined with k_read
+
+// MODE (own symbols, so that a kernel trace tells them apart):
+//   COLS_PLAIN     the transform
+//   COLS_ROWLIMIT  rows above *P.last_row_dev are not stored
+//   COLS_READ      extraction: nothing is stored at all -- the tile is parked in LDS and the bits of the bins
+//                  bucketed to it (P.rd_*) are read there (replaces the spectrum write + k_read's scattered reads)
+enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2 };
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN>
 __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -601,7 +607,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             v[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
         }
     };
-    const int out_rows = ROWLIMIT ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
+    const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     float2 u[E], un[E];
     load_tile(tile0, u);
     float2 W[tw_regs<L, E>()];
@@ -614,6 +620,29 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
     for (int tile = tile0; tile < tile1; tile++) {
         if (tile + 1 < tile1) load_tile(tile + 1, un);
         fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
+        if (MODE == COLS_READ) {
+            // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
+            __syncthreads();            // the last gather of fft_block has been consumed by every thread
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
+            __syncthreads();
+            if (g < P.G) {
+                const unsigned b = (unsigned)((plane * P.G + g) * ntiles + tile);
+                const unsigned e0 = P.rd_off[b], e1 = P.rd_off[b + 1];
+                uint8_t* bo = P.rd_bits + (size_t)img * P.rd_n;
+                const int tid = t * C + c, nthr = T * C;
+                for (unsigned e = e0 + tid; e < e1; e += nthr) {
+                    const TileBin tb = P.rd_bins[e];
+                    float2 v = lds[lay.idx(tb.k, tb.c)];
+                    if (tb.conj) v = cconj(v);
+                    bo[tb.bit] = (uint8_t)(P.rd_generic ? read_bit_value(v, *P.rd_ep, plane, P.rd_jitter, tb.bit) : (v.y >= 0.0f ? 1 : 0));
+                }
+            }
+            __syncthreads();            // before the next tile's exchanges overwrite the parked values
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = un[m];
+            continue;
+        }
         const int col = tile * C + c;
         if ((col < P.M) && (g < P.G)) {
             float2* dst = out + plane_off + col;
@@ -711,6 +740,22 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     spec[r.idx] = r.conj ? cconj(nv) : nv;    // the Hermitian mirror is implicit in the half spectrum
 }
 
+// read_bit_from_bin S:734-746 for one (already conjugate-corrected) bin value
+__device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, int p, const float* __restrict__ jitter, uint64_t j) {
+    if (!P.generic) return (v.y >= 0.0f) ? 1 : 0;     // nearer of +a / -a for 0 < a < pi, ties -> 1
+    const double PI = 3.14159265358979323846;
+    const double th = atan2((double)v.y, (double)v.x);
+    double alpha = P.alpha;
+    if (P.adaptive) {
+        const double mag = fmax(1e-12, (double)mag_of(v));
+        alpha *= fmin(2.0, fmax(0.5, mag / fmax(1e-12, P.med[p])));
+    }
+    const double jt = jitter ? (double)jitter[j] : 0.0;
+    double dp = fmod(th - (jt + alpha) + PI, 2 * PI); if (dp < 0) dp += 2 * PI; dp = fabs(dp - PI);
+    double dn = fmod(th - (jt - alpha) + PI, 2 * PI); if (dn < 0) dn += 2 * PI; dn = fabs(dn - PI);
+    return (dp <= dn) ? 1 : 0;
+}
+
 // read_bit_from_bin S:734-746 over a bin list.
 __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restrict__ bins,
                        const float* __restrict__ jitter, EmbedParams P, uint8_t* __restrict__ bits_out,
@@ -731,23 +776,140 @@ __global__ void k_read(const float2* __restrict__ spec, const tfft_bin* __restri
     const BinRef r = locate(p, y, x, P.PH, P.PW);
     float2 v = spec[r.idx];
     if (r.conj) v = cconj(v);
-    int bit;
-    if (!P.generic) {
-        bit = (v.y >= 0.0f) ? 1 : 0;     // nearer of +a / -a for 0 < a < pi, ties -> 1
-    } else {
-        const double PI = 3.14159265358979323846;
-        const double th = atan2((double)v.y, (double)v.x);
-        double alpha = P.alpha;
-        if (P.adaptive) {
-            const double mag = fmax(1e-12, (double)mag_of(v));
-            alpha *= fmin(2.0, fmax(0.5, mag / fmax(1e-12, P.med[p])));
-        }
-        const double jt = jitter ? (double)jitter[j] : 0.0;
-        double dp = fmod(th - (jt + alpha) + PI, 2 * PI); if (dp < 0) dp += 2 * PI; dp = fabs(dp - PI);
-        double dn = fmod(th - (jt - alpha) + PI, 2 * PI); if (dn < 0) dn += 2 * PI; dn = fabs(dn - PI);
-        bit = (dp <= dn) ? 1 : 0;
+    bits_out[j] = (uint8_t)read_bit_value(v, P, p, jitter, j);
+}
+
+// ---------------------------------------------------------------------------
+// Tile buckets for the spectrum-free extraction: the final forward column step holds a 16-column x L-row
+// tile of the final spectrum in LDS (rows y = g + G*k of group g); bucket b = (plane*G + g)*ntiles + tile
+// lists the bins of the walk that live in that tile, so the kernel reads their bits there and the
+// spectrum is never written.  count -> exclusive scan -> fill (order inside a bucket is irrelevant).
+// Invalid bins (off grid / on an excluded axis) set the error flag and are left out (their bits stay 0).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool tile_bin_of(const tfft_bin bn, int PH, int PW, int G, unsigned& bucket, TileBin& tb) {
+    const int x = bn.x, y = bn.y, p = bn.plane;
+    if (p > 2 || x >= PW || y >= PH || x == 0 || y == 0 || 2 * x == PW || 2 * y == PH) return false;
+    const int M = PW >> 1, ntiles = (M + 15) >> 4;
+    const bool conj = x > M;
+    const int xs = conj ? PW - x : x, ys = conj ? ((PH - y) & (PH - 1)) : y;
+    const int g = ys % G;
+    bucket = (unsigned)((p * G + g) * ntiles + (xs >> 4));
+    tb.k = (uint16_t)(ys / G); tb.c = (uint8_t)(xs & 15); tb.conj = conj ? 1 : 0; tb.bit = 0;
+    return true;
+}
+// Every workgroup takes a CONTIGUOUS chunk of the list.  When the chunk's buckets span fewer than
+// BUCKET_LCAP ids -- always, for a list in address order, whose neighbours share rows: that is why the bucket
+// id puts the tile last -- it counts in an LDS histogram of that span and touches each global counter once.
+// The first version added every bin to the global counters directly: at any moment all workgroups were on the
+// same few rows, and 231 000 atomics on ~150 hot addresses took 137 us (count) + 206 us (fill) per call.
+// Chunks with a wide span (a list in walk order) use global atomics, which such a list scatters by itself.
+constexpr unsigned BUCKET_LCAP = 8192;
+__device__ __forceinline__ bool bucket_span(const tfft_bin* __restrict__ bins, uint64_t lo, uint64_t hi, int PH, int PW, int G,
+                                            unsigned* mm, unsigned& bmin, unsigned& width, int* err) {
+    if (threadIdx.x == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
+    __syncthreads();
+    unsigned tmin = 0xFFFFFFFFu, tmax = 0u;          // per thread first: 4096 LDS atomics on two addresses cost ~25 us per workgroup
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        unsigned b; TileBin tb;
+        if (tile_bin_of(bins[i], PH, PW, G, b, tb)) { tmin = b < tmin ? b : tmin; tmax = b > tmax ? b : tmax; }
+        else if (err) atomicOr(err, 1);
     }
-    bits_out[j] = (uint8_t)bit;
+    if (tmin <= tmax) { atomicMin(&mm[0], tmin); atomicMax(&mm[1], tmax); }
+    __syncthreads();
+    bmin = mm[0];
+    const unsigned bmax = mm[1];
+    width = (bmin <= bmax) ? bmax - bmin + 1 : 0;
+    return width > 0 && width <= BUCKET_LCAP;
+}
+__global__ void k_bucket_count(const tfft_bin* __restrict__ bins, uint64_t n, int PH, int PW, int G, unsigned* __restrict__ cnt,
+                               int* __restrict__ err, int force_global) {
+    unsigned* lc = reinterpret_cast<unsigned*>(tfft_smem);        // [BUCKET_LCAP] + min/max
+    unsigned* mm = lc + BUCKET_LCAP;
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (uint64_t)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned bmin, width;
+    const bool local = bucket_span(bins, lo, hi, PH, PW, G, mm, bmin, width, err) && !force_global;
+    if (local) {
+        for (unsigned i = threadIdx.x; i < width; i += blockDim.x) lc[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        unsigned b; TileBin tb;
+        if (tile_bin_of(bins[i], PH, PW, G, b, tb)) atomicAdd(local ? &lc[b - bmin] : &cnt[b], 1u);
+    }
+    if (local) {
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < width; i += blockDim.x) if (lc[i]) atomicAdd(&cnt[bmin + i], lc[i]);
+    }
+}
+// exclusive scan of the bucket counts in three small launches (a single workgroup walking 49 152 counters took
+// 119 us): A: every workgroup scans its 1024 counters in LDS and publishes its total; B: one workgroup scans the
+// <= 1024 totals; C: every workgroup adds its prefix.  cnt is reset to 0 (the fill uses it as the cursor).
+__global__ void k_bucket_scan_a(unsigned* __restrict__ cnt, unsigned* __restrict__ off, unsigned* __restrict__ totals, int nb) {
+    unsigned* sh = reinterpret_cast<unsigned*>(tfft_smem);        // [1024]
+    const int t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    const unsigned v = (i < nb) ? cnt[i] : 0u;
+    if (i < nb) cnt[i] = 0;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                          // Hillis-Steele inclusive scan
+        const unsigned a = (t >= d) ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    if (i < nb) off[i] = sh[t] - v;
+    if (t == 1023) totals[blockIdx.x] = sh[t];
+}
+__global__ void k_bucket_scan_b(unsigned* __restrict__ totals, int nblk, unsigned* __restrict__ off, int nb) {
+    unsigned* sh = reinterpret_cast<unsigned*>(tfft_smem);
+    const int t = threadIdx.x;
+    const unsigned v = (t < nblk) ? totals[t] : 0u;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned a = (t >= d) ? sh[t - d] : 0u;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    if (t < nblk) totals[t] = sh[t] - v;                          // exclusive prefix of the workgroup totals
+    if (t == 1023) off[nb] = sh[t];
+}
+__global__ void k_bucket_scan_c(unsigned* __restrict__ off, const unsigned* __restrict__ totals, int nb) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nb) off[i] += totals[blockIdx.x];
+}
+// same chunking as k_bucket_count: count locally, reserve one range per non-zero bucket with ONE global atomic,
+// then place the chunk's bins with LDS atomics
+__global__ void k_bucket_fill(const tfft_bin* __restrict__ bins, const uint32_t* __restrict__ bit_index, uint64_t n, int PH, int PW,
+                              int G, unsigned* __restrict__ cursor, const unsigned* __restrict__ off, TileBin* __restrict__ out,
+                              int force_global) {
+    unsigned* lc = reinterpret_cast<unsigned*>(tfft_smem);        // [BUCKET_LCAP] local count, then this workgroup's cursor into the bucket
+    unsigned* mm = lc + BUCKET_LCAP;
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (uint64_t)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    unsigned bmin, width;
+    const bool local = bucket_span(bins, lo, hi, PH, PW, G, mm, bmin, width, nullptr) && !force_global;
+    if (local) {
+        for (unsigned i = threadIdx.x; i < width; i += blockDim.x) lc[i] = 0;
+        __syncthreads();
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            unsigned b; TileBin tb;
+            if (tile_bin_of(bins[i], PH, PW, G, b, tb)) atomicAdd(&lc[b - bmin], 1u);
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < width; i += blockDim.x) {
+            const unsigned k = lc[i];
+            if (k) lc[i] = off[bmin + i] + atomicAdd(&cursor[bmin + i], k);      // start of this workgroup's range in the bucket
+        }
+        __syncthreads();
+    }
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        unsigned b; TileBin tb;
+        if (!tile_bin_of(bins[i], PH, PW, G, b, tb)) continue;
+        tb.bit = bit_index ? bit_index[i] : (uint32_t)i;
+        const unsigned pos = local ? atomicAdd(&lc[b - bmin], 1u) : off[b] + atomicAdd(&cursor[b], 1u);
+        out[pos] = tb;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1289,7 +1451,7 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
     return hipSuccess;
 }
 
-template <int LOGL, int SIGN, bool ROWLIMIT = false>
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN>
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -1299,7 +1461,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const size_t lds = (size_t)gpb * L * C * sizeof(float2);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
-    auto k = k_fft_cols<LOGL, SIGN, ROWLIMIT>;
+    auto k = k_fft_cols<LOGL, SIGN, MODE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1310,16 +1472,36 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s) {
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
-    if (P.last_row_dev && sign < 0) return hipErrorInvalidValue;      // the row limit exists for the forward direction only
+    if ((P.last_row_dev || P.rd_bins) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
 #define F(n)                                                                            \
     return sign < 0 ? launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s) \
-         : P.last_row_dev ? launch_cols_t<(n <= 10 ? n : 10), +1, true>(in, out, tw_ph, P, n_planes, s) \
+         : P.rd_bins ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_READ>(in, out, tw_ph, P, n_planes, s) \
+         : P.last_row_dev ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_ROWLIMIT>(in, out, tw_ph, P, n_planes, s) \
                           : launch_cols_t<(n <= 10 ? n : 10), +1>(in, out, tw_ph, P, n_planes, s)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
     return hipSuccess;
 }
 
+hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, uint64_t n, int PH, int PW, int G,
+                              unsigned* cnt, unsigned* off, TileBin* out, int* err, int force_global, hipStream_t s) {
+    const int M = PW >> 1, ntiles = (M + 15) >> 4, nb = 3 * ntiles * G;
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)nb * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    unsigned blocks = (unsigned)((n + 2047) / 2048);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    const size_t lds = (BUCKET_LCAP + 2) * sizeof(unsigned);
+    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), lds, s, bins, n, PH, PW, G, cnt, err, force_global);
+    const int nblk = (nb + 1023) / 1024;                          // <= 1024 for every grid up to 16384^2 (3*512*64 buckets / 1024 = 96)
+    if (nblk > 1024) return hipErrorInvalidValue;
+    unsigned* totals = off + nb + 1;                              // the offsets buffer holds nb + 1 + nblk words
+    hipLaunchKernelGGL(k_bucket_scan_a, dim3(nblk), dim3(1024), 1024 * sizeof(unsigned), s, cnt, off, totals, nb);
+    hipLaunchKernelGGL(k_bucket_scan_b, dim3(1), dim3(1024), 1024 * sizeof(unsigned), s, totals, nblk, off, nb);
+    hipLaunchKernelGGL(k_bucket_scan_c, dim3(nblk), dim3(1024), 0, s, off, totals, nb);
+    hipLaunchKernelGGL(k_bucket_fill, dim3(blocks), dim3(256), lds, s, bins, bit_index, n, PH, PW, G, cnt, off, out, force_global);
+    return hipGetLastError();
+}
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s) {
     hipError_t e = hipMemsetAsync(last_row, 0, sizeof(int), s);
     if (e != hipSuccess || n == 0) return e;

@@ -74,6 +74,8 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
+static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p |= v; return o; }
 

@@ -97,7 +97,11 @@ def test_batch_matches_single(emu, orc):
     out = np.zeros_like(imgs)
     usable = np.zeros(nimg, np.uint64)
     raw = np.zeros((nimg, n), np.uint8)
-    ctx = B.Context(w, h, slots=3, lib=emu)
+    os.environ["TFFT_TILE_READ"] = "3"                   # tile-resident extraction also for chunks of < 8 images
+    try:
+        ctx = B.Context(w, h, slots=3, lib=emu)
+    finally:
+        del os.environ["TFFT_TILE_READ"]
     ctx.embed_batch_dev(nimg, imgs.ctypes.data, w, h, bins.ctypes.data, bits.ctypes.data, n, out.ctypes.data,
                         usable_ptr=usable.ctypes.data)
     ctx.extract_batch_dev(nimg, out.ctypes.data, w, h, bins.ctypes.data, n, raw.ctypes.data)
@@ -123,7 +127,33 @@ def test_batch_matches_single(emu, orc):
     ctx.extract_batch_dev(nimg, out2.ctypes.data, w, h, sbins.ctypes.data, n, raw2.ctypes.data)
     ctx.sync()
     assert np.array_equal(out2, out) and np.array_equal(usable2, usable) and np.array_equal(raw2, raw)
-    ctx.close()
+    # extraction reads the bits out of the LDS-resident column tiles (no spectrum); TFFT_TILE_READ=0 keeps the
+    # row-limited spectrum + k_read: same bits, also on the generic path (alpha outside (0, pi))
+    os.environ["TFFT_TILE_READ"] = "0"
+    try:
+        old = B.Context(w, h, slots=3, lib=emu)
+    finally:
+        del os.environ["TFFT_TILE_READ"]
+    old.set_bit_index(idx)
+    for alpha in (0.5, 3.5):
+        ra = np.zeros((nimg, n), np.uint8); rb = np.full((nimg, n), 7, np.uint8)
+        ctx.extract_batch_dev(nimg, out2.ctypes.data, w, h, sbins.ctypes.data, n, ra.ctypes.data, alpha=alpha)
+        old.extract_batch_dev(nimg, out2.ctypes.data, w, h, sbins.ctypes.data, n, rb.ctypes.data, alpha=alpha)
+        ctx.sync(); old.sync()
+        assert np.array_equal(ra, rb), alpha
+        if alpha == 0.5:
+            assert np.array_equal(ra, raw)
+    old.close(); ctx.close()
+    os.environ["TFFT_TILE_READ"] = "2"                   # the bucket build without LDS histograms (huge grids)
+    try:
+        g2 = B.Context(w, h, slots=3, lib=emu)
+    finally:
+        del os.environ["TFFT_TILE_READ"]
+    rc = np.zeros((nimg, n), np.uint8)
+    g2.extract_batch_dev(nimg, out.ctypes.data, w, h, bins.ctypes.data, n, rc.ctypes.data)
+    g2.sync()
+    assert np.array_equal(rc, raw)
+    g2.close()
 
 
 def test_unaligned_device_pointers(emu):

@@ -256,7 +256,11 @@ def test_batch_matches_single(lib, orc):
     d_usable = torch.zeros(nimg, dtype=torch.int64, device=dev)
     d_raw = torch.empty((nimg, n), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    ctx = B.Context(w, h, slots=3, lib=lib)
+    os.environ["TFFT_TILE_READ"] = "3"                   # tile-resident extraction also for chunks of < 8 images
+    try:
+        ctx = B.Context(w, h, slots=3, lib=lib)
+    finally:
+        del os.environ["TFFT_TILE_READ"]
     ctx.embed_batch_dev(nimg, d_img.data_ptr(), w, h, d_bins.data_ptr(), d_bits.data_ptr(), n, d_out.data_ptr(),
                         usable_ptr=d_usable.data_ptr())
     ctx.extract_batch_dev(nimg, d_out.data_ptr(), w, h, d_bins.data_ptr(), n, d_raw.data_ptr())
@@ -301,6 +305,23 @@ def test_batch_matches_single(lib, orc):
     assert np.array_equal(d_o8.cpu().numpy()[:5], out) and np.array_equal(d_r8.cpu().numpy()[:5], raw)
     assert np.array_equal(d_o8.cpu().numpy()[5:], out[:3])
     c2.close()
+    # default heuristic: a chunk of 8 images is extracted out of the tiles; the same with the spectrum + k_read path,
+    # also on the generic read path (alpha outside (0, pi)) and with the bins in walk order
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["TFFT_TILE_READ"] = mode
+        try:
+            c3 = B.Context(w, h, slots=8, lib=lib)
+        finally:
+            del os.environ["TFFT_TILE_READ"]
+        for alpha in (0.5, 3.5):
+            r = torch.zeros((8, n), dtype=torch.uint8, device=dev)
+            c3.extract_batch_dev(8, d_o8.data_ptr(), w, h, d_bins.data_ptr(), n, r.data_ptr(), alpha=alpha)
+            c3.sync()
+            res[(mode, alpha)] = r.cpu().numpy()
+        c3.close()
+    assert np.array_equal(res[("1", 0.5)], res[("0", 0.5)]) and np.array_equal(res[("1", 3.5)], res[("0", 3.5)])
+    assert np.array_equal(res[("1", 0.5)][:5], raw)
 
 
 def test_host_batch_pipeline(lib, orc):
