@@ -236,3 +236,33 @@ def test_bit_index_address_order(emu, orc):
 def test_audit64_is_the_reference_fft_bit_for_bit(emu, orc):
     PC.check_audit64_against_oracle(emu, orc, [(64, 64), (48, 40), (100, 30), (16, 1), (1, 8)])
     PC.check_product_against_audit64(emu, 200, 96)
+
+
+@pytest.mark.parametrize("wh", [(40, 300), (2040, 130), (100, 64)])
+def test_tile_resident_extraction_over_the_column_plans(emu, orc, wh):
+    """Spectrum-free batched extraction (bins bucketed per tile, bits read in LDS by the last forward column step)
+    against the spectrum + k_read path for a two-step column plan (PH = 512), the fused rows+columns plan
+    (PW = 2048) and a direct plan whose half width is not a multiple of the 16-column tile."""
+    from steganosaurus_amd.synth import cover_rgb
+    w, h = wh
+    nimg, n = 2, 200
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, lib=emu).next(n)
+    sbins, idx = B.bins_sort(bins, lib=emu)
+    imgs = np.stack([cover_rgb(w, h, 20 + i) for i in range(nimg)])
+    res = []
+    for mode, bl, index in (("3", sbins, idx), ("0", sbins, idx), ("3", bins, None), ("2", bins, None)):
+        os.environ["TFFT_TILE_READ"] = mode
+        try:
+            ctx = B.Context(w, h, slots=nimg, lib=emu)
+        finally:
+            del os.environ["TFFT_TILE_READ"]
+        if index is not None:
+            ctx.set_bit_index(index)
+        raw = np.full((nimg, n), 9, np.uint8)
+        ctx.extract_batch_dev(nimg, imgs.ctypes.data, w, h, bl.ctypes.data, n, raw.ctypes.data)
+        ctx.sync(); ctx.close()
+        res.append(raw)
+    for r in res[1:]:
+        assert np.array_equal(r, res[0])
+    assert set(np.unique(res[0])) <= {0, 1}
