@@ -266,3 +266,29 @@ def test_tile_resident_extraction_over_the_column_plans(emu, orc, wh):
     for r in res[1:]:
         assert np.array_equal(r, res[0])
     assert set(np.unique(res[0])) <= {0, 1}
+
+
+def test_tile_resident_extraction_buffers_grow_and_shrink(emu, orc):
+    """One context, bin lists of growing and shrinking length (the bucket buffers are reallocated on demand) and
+    two geometries in turn: always the bits of the spectrum + k_read path."""
+    from steganosaurus_amd.synth import cover_rgb
+    ctxs = []
+    for mode in ("3", "0"):
+        os.environ["TFFT_TILE_READ"] = mode
+        try:
+            ctxs.append(B.Context(200, 96, slots=2, lib=emu))
+        finally:
+            del os.environ["TFFT_TILE_READ"]
+    for (w, h, n) in [(64, 48, 60), (200, 96, 4000), (64, 48, 900), (200, 80, 10)]:
+        ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+        bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, lib=emu).next(n)
+        imgs = np.stack([cover_rgb(w, h, 3 + i) for i in range(2)])
+        out = []
+        for c in ctxs:
+            raw = np.full((2, n), 5, np.uint8)
+            c.extract_batch_dev(2, imgs.ctypes.data, w, h, bins.ctypes.data, n, raw.ctypes.data)
+            c.sync()
+            out.append(raw)
+        assert np.array_equal(out[0], out[1]), (w, h, n)
+    for c in ctxs:
+        c.close()
