@@ -608,8 +608,25 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         }
     };
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
+    // COLS_READ: the buckets of this workgroup's tiles are consecutive (tile is the last digit of the bucket id), so
+    // nine offsets tell which tiles carry bins at all; a tile without bins (beyond the annulus: a tenth of them with
+    // rmax = 0.45) is neither loaded nor transformed.  Workgroup-uniform, so the barriers stay aligned.
+    unsigned eoff[9];
+    if (MODE == COLS_READ) {
+        const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
+#pragma unroll
+        for (int i = 0; i < 9; i++) eoff[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
+    }
+    auto has_bins = [&](int tile) -> bool {
+        if (MODE != COLS_READ || P.tiles_per_block > 8 || blockDim.z > 1) return true;
+        const int i = tile - tile0;
+        bool r = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k == i) r = eoff[k + 1] > eoff[k];
+        return r;
+    };
     float2 u[E], un[E];
-    load_tile(tile0, u);
+    if (has_bins(tile0)) load_tile(tile0, u);
     float2 W[tw_regs<L, E>()];
     fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
     float2 wo[E];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
@@ -618,7 +635,12 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         for (int m = 0; m < E; m++) wo[m] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
     }
     for (int tile = tile0; tile < tile1; tile++) {
-        if (tile + 1 < tile1) load_tile(tile + 1, un);
+        if (tile + 1 < tile1 && has_bins(tile + 1)) load_tile(tile + 1, un);
+        if (!has_bins(tile)) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = un[m];
+            continue;
+        }
         fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
