@@ -250,12 +250,10 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     for (int i = 0; i < NT; i++) tv[i] = tw[2 * (n1 * T + t + i * T * N1)];
     float2 cv = make_float2(0.f, 0.f);
     if (n1 == 0 && t < N1) cv = tw_h[(n2 * t) & (P.PH - 1)];
-    constexpr int NSPLIT = (M / 2) / T + 1;
-    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW): lane-only indices
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
-    }
+    // split twiddle exp(+2 pi i x/PW) of the column pair (x, M-x) this thread finishes in the column phase:
+    // x = n1*T + t in [0, M/2); thread 0 owns the packed column 0 and the self-paired column M/2
+    const int px = n1 * T + t;
+    const float2 wsx = tw[px], wsh = tw[M / 2];
     const uint8_t* src = rgb + ((size_t)img * P.H + (live ? y : 0)) * (size_t)(P.W * 3);
     const bool fastp = live && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
     constexpr int GMAX = (2 * M / 4) / T;               // 4-pixel groups per lane
@@ -302,45 +300,48 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
         // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
         fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
 #pragma unroll
-        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];
-        WaveSync::sync();
-        // split in place: the pair (k, M-k) is read and rewritten by the same thread
-#pragma unroll
-        for (int j = 0; j < NSPLIT; j++) {
-            const int k = t + j * T;
-            if (k > M / 2) break;
-            const int k2 = (M - k) & (M - 1);
-            const float2 zk = lds[lay.idx(k, n1)], zm = lds[lay.idx(k2, n1)];
-            const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-            const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);
-            const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);
-            const float2 b = cmul(wk[j], od);
-            if (k == 0) {
-                lds[lay.idx(0, n1)] = make_float2(a.x + b.x, a.x - b.x);
-            } else {
-                lds[lay.idx(k, n1)] = cadd(a, b);
-                if (k2 != k) lds[lay.idx(k2, n1)] = cconj(csub(a, b));
-            }
-        }
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];      // Z = FFT of the packed (even, odd) row
     } else {
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = make_float2(0.f, 0.f);
     }
     __syncthreads();
 
-    // ---- length-N1 DFT across the rows, per column; output row k1*N2 + n2, times exp(+2 pi i n2 k1/PH)
+    // ---- real-FFT split and length-N1 DFT across the rows in one go, per column PAIR (x, M-x): the split
+    // X[x] = Ev + w^x Od, X[M-x] = conj(Ev - w^x Od) needs Z[x] and Z[M-x] of the same row, and w^x is the same for
+    // all N1 rows, so the thread that owns the pair loads both columns once (a separate in-place split pass cost
+    // four more LDS accesses per bin and nine twiddle registers per row thread).  M/2 threads, one pair each;
+    // output row k1*N2 + n2, times exp(+2 pi i n2 k1/PH).
+    static_assert(T * N1 == M / 2, "one column pair per thread");
     float2 wc[N1];                      // from the LDS copy made at the top: as global loads here they were a
 #pragma unroll                          // full memory round trip between the barrier and the first store
     for (int k1 = 0; k1 < N1; k1++) wc[k1] = lwc[k1];
     float2* dst = out + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
-    for (int x = n1 * T + t; x < M; x += T * N1) {
-        float2 v[N1];
+    const int xa = px, xb = (px == 0) ? M / 2 : M - px;       // thread 0: packed column 0, then the self-paired column M/2
+    float2 va[N1], vb[N1];
 #pragma unroll
-        for (int r = 0; r < N1; r++) v[r] = lds[lay.idx(x, r)];
-        DftReg<N1, +1, 0, N1>::run(v);
+    for (int r = 0; r < N1; r++) {
+        const float2 zk = lds[lay.idx(xa, r)], zm = lds[lay.idx((M - xa) & (M - 1), r)];
+        const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // Ev[x]
+        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                        // zk - conj(zm)
+        const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);                        // Od[x] = d/(2i)
+        const float2 b = cmul(wsx, od);
+        va[r] = cadd(a, b);
+        vb[r] = cconj(csub(a, b));
+        if (px == 0) {
+            va[r] = make_float2(a.x + b.x, a.x - b.x);                                 // X[0] and X[M], both real, packed
+            const float2 zh = lds[lay.idx(M / 2, r)];                                  // column M/2 pairs with itself
+            const float2 ah = make_float2(zh.x, 0.0f), dh = make_float2(0.0f, 2.0f * zh.y);
+            const float2 odh = make_float2(0.5f * dh.y, -0.5f * dh.x);
+            vb[r] = cadd(ah, cmul(wsh, odh));
+        }
+    }
+    DftReg<N1, +1, 0, N1>::run(va);
+    DftReg<N1, +1, 0, N1>::run(vb);
 #pragma unroll
-        for (int k1 = 0; k1 < N1; k1++)
-            dst[(size_t)k1 * N2 * M + x] = cmul(v[bitrev(k1, LOGN1)], wc[k1]);
+    for (int k1 = 0; k1 < N1; k1++) {
+        dst[(size_t)k1 * N2 * M + xa] = cmul(va[bitrev(k1, LOGN1)], wc[k1]);
+        dst[(size_t)k1 * N2 * M + xb] = cmul(vb[bitrev(k1, LOGN1)], wc[k1]);
     }
 }
 
