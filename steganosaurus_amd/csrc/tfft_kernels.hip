@@ -386,48 +386,41 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
 #pragma unroll
     for (int i = 0; i < NT; i++) tv[i] = tw[2 * (n1 * T + t + i * T * N1)];
 
-    // split twiddles exp(+2 pi i k/PW), k = t + 64 j <= M/2, fetched ahead of the column phase
-    constexpr int NSPLIT = (M / 2) / T + 1;
-    float2 wsp[NSPLIT];
-    if (y < P.H) {
-#pragma unroll
-        for (int j = 0; j < NSPLIT; j++) wsp[j] = tw[imin(t + j * T, M / 2)];
-    }
-
-    // ---- length-N1 inverse DFT across the rows, per column
+    // ---- length-N1 inverse DFT across the rows and the half-spectrum -> packed-row split in one go, per column
+    // PAIR (x, M-x) (mirror image of k_rowcol_fwd): Z[x] = Ev + i Od, Z[M-x] = conj(Ev) + i conj(Od) with
+    // Ev = (X[x] + conj X[M-x])/2, Od = (X[x] - conj X[M-x])/2 * w^-x, and w^x is shared by the N1 rows.  One pair
+    // per thread; thread 0 owns the packed column 0 and the self-paired column M/2.  Rows >= H are not stored.
+    static_assert(T * N1 == M / 2, "one column pair per thread");
+    const int px = n1 * T + t;
+    const int xa = px, xb = (px == 0) ? M / 2 : M - px;
+    const float2 wsx = tw[px], wsh = tw[M / 2];
     const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
-    for (int x = n1 * T + t; x < M; x += T * N1) {
-        float2 v[N1];
+    float2 va[N1], vb[N1];
 #pragma unroll
-        for (int k1 = 0; k1 < N1; k1++) v[k1] = src[(size_t)k1 * N2 * M + x];
-        DftReg<N1, -1, 0, N1>::run(v);
+    for (int k1 = 0; k1 < N1; k1++) { va[k1] = src[(size_t)k1 * N2 * M + xa]; vb[k1] = src[(size_t)k1 * N2 * M + xb]; }
+    DftReg<N1, -1, 0, N1>::run(va);
+    DftReg<N1, -1, 0, N1>::run(vb);
 #pragma unroll
-        for (int r = 0; r < N1; r++) lds[lay.idx(x, r)] = v[bitrev(r, LOGN1)];
+    for (int r = 0; r < N1; r++) {
+        if (r * N2 + n2 >= P.H) continue;                     // workgroup uniform
+        const float2 xk = va[bitrev(r, LOGN1)], xm = vb[bitrev(r, LOGN1)];
+        if (px == 0) {
+            lds[lay.idx(0, r)] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));      // X[0], X[M] packed in bin 0
+            const float2 od = cmul(make_float2(0.0f, xm.y), cconj(wsh));                       // column M/2 pairs with itself
+            lds[lay.idx(M / 2, r)] = make_float2(xm.x - od.y, 0.0f + od.x);
+        } else {
+            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 od = cmul(d, cconj(wsx));
+            lds[lay.idx(xa, r)] = make_float2(ev.x - od.y, ev.y + od.x);
+            lds[lay.idx(xb, r)] = make_float2(ev.x + od.y, od.x - ev.y);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
     __syncthreads();
     if (y >= P.H) return;               // wave uniform (one wave per row); no barrier follows
 
-    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k, done IN PLACE
-    // in LDS one pair (k, M-k) at a time: Ev[M-k] = conj Ev[k] and Od[M-k] = conj Od[k] (w^M = -1), so the pair
-    // shares its loads, its twiddle and half its arithmetic.  Building all 16 of a thread's Z in registers
-    // instead kept 48 loads in flight and the kernel at 146 VGPRs, i.e. ONE workgroup per CU.
-#pragma unroll
-    for (int j = 0; j < NSPLIT; j++) {
-        const int k = t + j * T;
-        if (k <= M / 2) {
-            const int k2 = (M - k) & (M - 1);
-            const float2 xk = lds[lay.idx(k, n1)], xm = lds[lay.idx(k2, n1)];
-            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(wsp[j]));
-            float2 zk = make_float2(ev.x - od.y, ev.y + od.x);
-            if (k == 0) zk = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));     // X[0], X[M] packed in bin 0
-            lds[lay.idx(k, n1)] = zk;
-            if (k2 != k) lds[lay.idx(k2, n1)] = make_float2(ev.x + od.y, od.x - ev.y);
-        }
-    }
     WaveSync::sync();
     float2 u[E];
 #pragma unroll
