@@ -472,33 +472,29 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
     using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
 
     const float2* src = in + (size_t)img * P.img_stride + ((size_t)(plane0 + pb) * P.PH + y) * M;
-    float2 xin[E];
+    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k, one pair (k, M-k)
+    // at a time straight from global memory (Ev[M-k] = conj Ev[k], Od[M-k] = conj Od[k]; see k_colrow_inv): both
+    // streams are coalesced (k ascending, M-k descending) and the packed row reaches LDS already split.
+    constexpr int NSPLIT = (M / 2) / T + 1;
+    float2 xk[NSPLIT], xm[NSPLIT], wk[NSPLIT];      // every load first (clamped, unpredicated), then the arithmetic
 #pragma unroll
-    for (int m = 0; m < E; m++) xin[m] = src[t + m * T];
+    for (int j = 0; j < NSPLIT; j++) {
+        const int k = imin(t + j * T, M / 2);
+        xk[j] = src[k]; xm[j] = src[(M - k) & (M - 1)]; wk[j] = tw[k];      // split twiddles exp(+2 pi i k/PW)
+    }
     constexpr bool LAZY = LOGM >= TFFT_ROWS_LAZY_LOG;      // see k_rows_fwd
     float2 W[LAZY ? 1 : tw_regs<M, E>()];
     if (!LAZY) fft_prefetch_twiddles<M, E, -1>(W, t, tw, 2);
-    constexpr int NSPLIT = (M / 2) / T + 1;
-    float2 wk[NSPLIT];                  // split twiddles exp(+2 pi i k/PW), k = t + j*T <= M/2
-#pragma unroll
-    for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
-#pragma unroll
-    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = xin[m];
-    Sync::sync();
-
-    // ---- Z[k] = Ev[k] + i Od[k]:  Ev = (X[k]+conj X[M-k])/2,  Od = (X[k]-conj X[M-k])/2 * w^-k, in place in LDS
-    // one pair (k, M-k) at a time (Ev[M-k] = conj Ev[k], Od[M-k] = conj Od[k]; see k_colrow_inv)
 #pragma unroll
     for (int j = 0; j < NSPLIT; j++) {
         const int k = t + j * T;
         if (k <= M / 2) {
             const int k2 = (M - k) & (M - 1);
-            const float2 xk = lds[lay.idx(k, pb)], xm = lds[lay.idx(k2, pb)];
-            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 ev = make_float2(0.5f * (xk[j].x + xm[j].x), 0.5f * (xk[j].y - xm[j].y));
+            const float2 d = make_float2(0.5f * (xk[j].x - xm[j].x), 0.5f * (xk[j].y + xm[j].y));
             const float2 od = cmul(d, cconj(wk[j]));
             float2 zk = make_float2(ev.x - od.y, ev.y + od.x);
-            if (k == 0) zk = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));     // X[0], X[M] packed in bin 0
+            if (k == 0) zk = make_float2(0.5f * (xk[j].x + xk[j].y), 0.5f * (xk[j].x - xk[j].y));     // X[0], X[M] packed in bin 0
             lds[lay.idx(k, pb)] = zk;
             if (k2 != k) lds[lay.idx(k2, pb)] = make_float2(ev.x + od.y, od.x - ev.y);
         }
