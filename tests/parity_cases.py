@@ -57,11 +57,11 @@ def spec_errors(got, want):
     return nrm, (err / (1e-4 * np.abs(want) + atol)).max(), rel
 
 
-def assert_spectrum_close(got, want, tag=""):
+def assert_spectrum_close(got, want, tag="", rel_bar=1e-4):
     nrm, mx, rel = spec_errors(got, want)
     assert nrm < 2e-6, (tag, "normwise", nrm)            # 50x inside the 1e-4 tolerance
     assert mx <= 1.0, (tag, "rtol 1e-4 + atol 1e-5*rms", mx)
-    assert rel < 1e-4, (tag, "per-coefficient", rel)     # the north_star tolerance
+    assert rel < rel_bar, (tag, "per-coefficient", rel)  # the north_star tolerance
 
 
 def check_fft_kat(lib):
@@ -235,7 +235,7 @@ def check_audit64_against_oracle(lib, orc, sizes):
     ctx.close()
 
 
-def check_product_against_audit64(lib, w, h, center=False, seed=7):
+def check_product_against_audit64(lib, w, h, center=False, seed=7, rel_bar=1e-4):
     """fp32 product spectrum against the fp64 audit transform of the same image, at any size (no CPU
     reference needed): the SURVEY 8c tolerance (1e-4 relative, see spec_errors)."""
     img = cover_rgb(w, h, seed)
@@ -245,7 +245,7 @@ def check_product_against_audit64(lib, w, h, center=False, seed=7):
     want = ctx.audit_forward_rgb8_f64(img, center=center)
     ctx.close()
     for p in range(3):
-        assert_spectrum_close(got[p], want[p], tag="%dx%d plane %d" % (w, h, p))
+        assert_spectrum_close(got[p], want[p], tag="%dx%d plane %d" % (w, h, p), rel_bar=rel_bar)
     return got, want
 
 

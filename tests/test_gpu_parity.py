@@ -410,3 +410,20 @@ def test_fp32_spectrum_against_fp64_audit_at_full_size(lib, wh):
     """BASELINE configs 2, 3 and 5 at FULL size: every coefficient of the fp32 product spectrum against the
     reference's own arithmetic (fp64 radix-2, evaluated on the device) -- the CPU oracle needs minutes here."""
     PC.check_product_against_audit64(lib, wh[0], wh[1], center=(wh[0] == 3840))
+
+
+def test_random_geometries_against_fp64_audit(lib):
+    """Seeded random image sizes (odd widths, single rows/columns, sizes straddling every plan boundary): the fp32
+    spectrum against the device fp64 audit transform (= the reference's arithmetic), and forward -> inverse = the
+    image itself.  The CPU oracle would need minutes for the larger ones; the audit transform makes this a
+    few seconds on the GPU box."""
+    rng = np.random.default_rng(20261004)
+    sizes = [(1, 1), (2, 1), (1, 2), (3, 5), (17, 1), (1, 300), (2047, 129), (2049, 127), (1023, 257), (4097, 3)]
+    sizes += [(int(w), int(h)) for w, h in zip(rng.integers(1, 2600, 14), rng.integers(1, 1400, 14))]
+    # every coefficient within 1e-4*|F| + 1e-5*rms and normwise < 2e-6 as everywhere else; the PURE relative figure
+    # over coefficients >= 0.1*rms gets 2.5e-4 here instead of 1e-4: in heavily padded images (2131x1179 -> 4096x2048)
+    # the bins one to four steps away from an excluded axis sit on the sidelobes of the DC term and reach 1.2-1.5e-4
+    # (tools/audit_diag.py: e.g. (y 1023, x 1)); at the BASELINE sizes the same figure is <= 5.5e-5.
+    for i, (w, h) in enumerate(sizes):
+        PC.check_product_against_audit64(lib, w, h, center=bool(i & 1), seed=100 + i, rel_bar=2.5e-4)
+    PC.check_identity_roundtrip(lib, sizes)

@@ -17,6 +17,9 @@ for p in range(3):
     score = err / (1e-4 * np.abs(want[p]) + 1e-5 * rms)
     off = np.ones(score.shape, bool); off[:, 0] = off[:, pw // 2] = False; off[0, :] = off[ph // 2, :] = False
     peak = max(abs(want[p][0, 0]), abs(want[p][ph // 2, 0]), abs(want[p][0, pw // 2]), abs(want[p][ph // 2, pw // 2]))
+    relm = np.where(off & (np.abs(want[p]) >= 0.1 * rms), err / np.maximum(np.abs(want[p]), 1e-300), 0.0)
+    iy, ix = np.unravel_index(np.argmax(relm), relm.shape)
+    print("plane", p, "worst off-axis pure-relative error among |F| >= 0.1 rms: %.3g at y %d x %d (|F|/rms %.3g)" % (relm[iy, ix], iy, ix, abs(want[p][iy, ix]) / rms))
     print("plane", p, "worst OFF-axis score %.3f; worst on-axis err %.3g*rms = %.3g ulp_fp32(peak)" % (score[off].max(), err[~off].max() / rms, err[~off].max() / (5.97e-8 * peak)))
     idx = np.argsort(score.ravel())[-6:][::-1]
     print("plane", p, "rms %.4g" % rms, "normwise %.3g" % (np.linalg.norm(got[p] - want[p]) / np.linalg.norm(want[p])))
