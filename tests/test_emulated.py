@@ -247,7 +247,10 @@ def test_tile_resident_extraction_over_the_column_plans(emu, orc, wh):
     w, h = wh
     nimg, n = 2, 200
     ph, pw = orc.next_pow2(h), orc.next_pow2(w)
-    bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, lib=emu).next(n)
+    # rmax = 0.95: part of the walk lies in the mirror half (x > PW/2), stored conjugated at (PH-y, PW-x)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, rmin=0.05, rmax=0.95, lib=emu).next(n)
+    if ph >= 4 * pw:        # tall grid: the annulus reaches beyond PW/2
+        assert (bins["x"] > pw // 2).any() and (bins["x"] < pw // 2).any()
     sbins, idx = B.bins_sort(bins, lib=emu)
     imgs = np.stack([cover_rgb(w, h, 20 + i) for i in range(nimg)])
     res = []
