@@ -15,6 +15,8 @@ struct RowParams {
     int center;      // (-1)^(x+y) pre/post multiply (apply_center)
     float scale;     // inverse only: 1/((PW/2)*PH)
     size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
+    float bias;          // forward only: subtracted from every pixel before the transform (its rank-1 transform is added
+                         // back by the last column step, ColParams::dc_*); 0 = off
 };
 
 // a bin of the list, located inside its column tile: value at LDS row `k` (= y / G), column `c` (= x % 16)
@@ -36,6 +38,10 @@ struct ColParams {
     const float* rd_jitter;          // per stream bit, or nullptr
     const struct EmbedParams* rd_ep; // device copy of the read parameters (generic path only dereferences it)
     int rd_generic;
+    // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
+    // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off
+    const float2* dc_ah;       // PH entries, the factor c included
+    const float2* dc_aw;       // M entries, entry 0 packed: A_W(0) + i*A_W(M)
     const int* last_row_dev;   // optional device scalar: rows > *last_row_dev are not stored either (extraction reads
                                // only the rows its bin list touches; k_bins_last_row)
     int tw_out;        // multiply output by exp(sign*2*pi*i*k*g/PH)

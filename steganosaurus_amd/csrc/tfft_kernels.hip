@@ -60,11 +60,11 @@ __device__ __forceinline__ void xcd_plane_order(int N2, int& n2, int& plane) {
 // p+6, p+9.  Two byte-aligned 32-bit windows hold them at byte 0 and byte 3 (v_alignbyte_b32 takes its
 // shift modulo 4, hence the select for p == 2), and byte -> float is one v_cvt_f32_ubyteN each: ~10
 // instructions per group instead of ~40 for variable 64-bit shifts.
-__device__ __forceinline__ void plane_samples4(uint32_t a, uint32_t b, uint32_t c, int p, float& v0, float& v1, float& v2, float& v3) {
+__device__ __forceinline__ void plane_samples4(uint32_t a, uint32_t b, uint32_t c, int p, float bias, float& v0, float& v1, float& v2, float& v3) {
     const uint32_t w0 = __builtin_amdgcn_alignbyte(b, a, (uint32_t)p);                         // bytes p .. p+3
     const uint32_t w1 = (p == 2) ? c : __builtin_amdgcn_alignbyte(c, b, (uint32_t)(p + 2));    // bytes p+6 .. p+9
-    v0 = (float)(w0 & 0xFFu); v1 = (float)(w0 >> 24);
-    v2 = (float)(w1 & 0xFFu); v3 = (float)(w1 >> 24);
+    v0 = (float)(w0 & 0xFFu) - bias; v1 = (float)(w0 >> 24) - bias;
+    v2 = (float)(w1 & 0xFFu) - bias; v3 = (float)(w1 >> 24) - bias;
 }
 
 // ---------------------------------------------------------------------------
@@ -116,7 +116,7 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
             const int g = tid + i * nthr;
             if (g < ng) {
                 float v0, v1, v2, v3;
-                plane_samples4(ra[i], rb[i], rc[i], plane0, v0, v1, v2, v3);
+                plane_samples4(ra[i], rb[i], rc[i], plane0, P.bias, v0, v1, v2, v3);
                 lds[lay.idx(2 * g, 0)] = make_float2(s0 * v0, s1 * v1);
                 lds[lay.idx(2 * g + 1, 0)] = make_float2(s0 * v2, s1 * v3);
             }
@@ -128,12 +128,13 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
         for (int g = tid; g < (P.W >> 2); g += nthr) {
             const uint32_t a = srcw[3 * g], b = srcw[3 * g + 1], c = srcw[3 * g + 2];   // R0G0B0R1 G1B1R2G2 B2R3G3B3
             const int i0 = lay.idx(2 * g, 0), i1 = lay.idx(2 * g + 1, 0);
-            lds[i0] = make_float2(s0 * (float)(a & 0xFF), s1 * (float)(a >> 24));
-            lds[i1] = make_float2(s0 * (float)((b >> 16) & 0xFF), s1 * (float)((c >> 8) & 0xFF));
-            lds[i0 + lay.pitch] = make_float2(s0 * (float)((a >> 8) & 0xFF), s1 * (float)(b & 0xFF));
-            lds[i1 + lay.pitch] = make_float2(s0 * (float)(b >> 24), s1 * (float)((c >> 16) & 0xFF));
-            lds[i0 + 2 * lay.pitch] = make_float2(s0 * (float)((a >> 16) & 0xFF), s1 * (float)((b >> 8) & 0xFF));
-            lds[i1 + 2 * lay.pitch] = make_float2(s0 * (float)(c & 0xFF), s1 * (float)(c >> 24));
+            const float bz = P.bias;
+            lds[i0] = make_float2(s0 * ((float)(a & 0xFF) - bz), s1 * ((float)(a >> 24) - bz));
+            lds[i1] = make_float2(s0 * ((float)((b >> 16) & 0xFF) - bz), s1 * ((float)((c >> 8) & 0xFF) - bz));
+            lds[i0 + lay.pitch] = make_float2(s0 * ((float)((a >> 8) & 0xFF) - bz), s1 * ((float)(b & 0xFF) - bz));
+            lds[i1 + lay.pitch] = make_float2(s0 * ((float)(b >> 24) - bz), s1 * ((float)((c >> 16) & 0xFF) - bz));
+            lds[i0 + 2 * lay.pitch] = make_float2(s0 * ((float)((a >> 16) & 0xFF) - bz), s1 * ((float)((b >> 8) & 0xFF) - bz));
+            lds[i1 + 2 * lay.pitch] = make_float2(s0 * ((float)(c & 0xFF) - bz), s1 * ((float)(c >> 24) - bz));
         }
         for (int m = (P.W >> 1) + tid; m < M; m += nthr) {      // zero padding W..PW-1
 #pragma unroll
@@ -145,7 +146,7 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
             const int n = off / 3, ch = off - 3 * n;
             const int b = ch - plane0;
             if (b < 0 || b >= PPB) return;
-            float v = (float)byte;
+            float v = (float)byte - P.bias;
             if (P.center && ((n + y) & 1)) v = -v;
             ldsf[2 * lay.idx(n >> 1, b) + (n & 1)] = v;
         };
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
             const int g = t + i * T;
             if (g < ng) {
                 float v0, v1, v2, v3;
-                plane_samples4(ra[i], rb[i], rc[i], plane, v0, v1, v2, v3);
+                plane_samples4(ra[i], rb[i], rc[i], plane, P.bias, v0, v1, v2, v3);
                 lds[lay.idx(2 * g, n1)] = make_float2(s0 * v0, s1 * v1);
                 lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * v2, s1 * v3);
             }
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     } else if (live) {
         for (int n = t; n < 2 * M; n += T) {
             float v = 0.0f;
-            if (n < P.W) { v = (float)src[3 * n + plane]; if (P.center && ((n + y) & 1)) v = -v; }
+            if (n < P.W) { v = (float)src[3 * n + plane] - P.bias; if (P.center && ((n + y) & 1)) v = -v; }
             ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
         }
     }
@@ -598,6 +599,15 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         }
     };
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
+    // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
+    float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
+    if (P.dc_ah) {
+        for (int k = t * C + c; k < L; k += T * C) {
+            const int row = P.out_a * k + P.out_b * g;
+            lds_ah[k] = (g < P.G && row < P.PH) ? P.dc_ah[row] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+    }
     // COLS_READ: the buckets of this workgroup's tiles are consecutive (tile is the last digit of the bucket id), so
     // nine offsets tell which tiles carry bins at all; a tile without bins (beyond the annulus: a tenth of them with
     // rmax = 0.45) is neither loaded nor transformed.  Workgroup-uniform, so the barriers stay aligned.
@@ -616,7 +626,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         return r;
     };
     float2 u[E], un[E];
-    if (has_bins(tile0)) load_tile(tile0, u);
+    // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
+    // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
+    float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
+    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (P.dc_ah && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     float2 W[tw_regs<L, E>()];
     fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
     float2 wo[E];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
@@ -625,16 +639,21 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         for (int m = 0; m < E; m++) wo[m] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
     }
     for (int tile = tile0; tile < tile1; tile++) {
-        if (tile + 1 < tile1 && has_bins(tile + 1)) load_tile(tile + 1, un);
+        if (tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
         if (!has_bins(tile)) {
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
+            awc = awn;
             continue;
         }
         fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
             __syncthreads();            // the last gather of fft_block has been consumed by every thread
+            if (P.dc_ah) {
+#pragma unroll
+                for (int m = 0; m < E; m++) u[m] = cadd(u[m], cmul(lds_ah[t + m * T], awc));
+            }
 #pragma unroll
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             __syncthreads();
@@ -653,6 +672,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             __syncthreads();            // before the next tile's exchanges overwrite the parked values
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
+            awc = awn;
             continue;
         }
         const int col = tile * C + c;
@@ -665,12 +685,14 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
                 if (row < out_rows) {
                     float2 v = u[m];
                     if (P.tw_out) v = cmul(v, wo[m]);
+                    if (P.dc_ah) v = cadd(v, cmul(lds_ah[k], awc));
                     dst[(size_t)row * P.M] = v;
                 }
             }
         }
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = un[m];
+        awc = awn;
     }
 }
 
@@ -1470,7 +1492,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    const size_t lds = (size_t)gpb * L * C * sizeof(float2);
+    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (P.dc_ah ? (size_t)gpb * L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE>;

@@ -249,6 +249,34 @@ def check_product_against_audit64(lib, w, h, center=False, seed=7, rel_bar=1e-4)
     return got, want
 
 
+def check_dc_removal(lib, sizes, ref_forward):
+    """TFFT_DC_BIAS=128: the forward transform of (pixel - 128) plus the analytic transform of the constant.  Against
+    the fp64 reference (ref_forward(img, center) -> complex128 spectrum) every OFF-axis coefficient must now be
+    within 1e-5*|F| + 1e-6*rms -- ten times tighter than the default path's bar -- and forward -> inverse must still
+    return the image (the inverse is unchanged and works on the true spectrum)."""
+    os.environ["TFFT_DC_BIAS"] = "128"
+    try:
+        for i, (w, h) in enumerate(sizes):
+            img = cover_rgb(w, h, 40 + i)
+            center = bool(i & 1)
+            ctx = B.Context(w, h, lib=lib)
+            pw, ph = ctx.forward_rgb8(img, center=center)
+            got = ctx.download_spectrum(pw, ph).astype(np.complex128)
+            assert np.array_equal(ctx.inverse_rgb8(w, h), img), (w, h)
+            ctx.close()
+            want = ref_forward(img, center)
+            for p in range(3):
+                err = np.abs(got[p] - want[p]); rms = max(1e-300, np.sqrt(np.mean(np.abs(want[p]) ** 2)))
+                off = np.ones(err.shape, bool); off[:, 0] = off[0, :] = False
+                off[:, pw // 2] = False; off[ph // 2, :] = False
+                if off.any():
+                    score = (err / (1e-5 * np.abs(want[p]) + 1e-6 * rms))[off].max()
+                    assert score <= 1.0, (w, h, p, "off-axis", score)
+                assert np.linalg.norm(got[p] - want[p]) / max(1e-300, np.linalg.norm(want[p])) < 1e-6, (w, h, p)
+    finally:
+        del os.environ["TFFT_DC_BIAS"]
+
+
 def check_identity_roundtrip(lib, sizes):
     """forward -> inverse with no embedding returns the cover exactly (integers survive fp32)."""
     for (w, h) in sizes:

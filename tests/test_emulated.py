@@ -295,3 +295,8 @@ def test_tile_resident_extraction_buffers_grow_and_shrink(emu, orc):
         assert np.array_equal(out[0], out[1]), (w, h, n)
     for c in ctxs:
         c.close()
+
+
+def test_dc_removal_option(emu, orc):
+    PC.check_dc_removal(emu, [(64, 64), (48, 40), (200, 96), (100, 300), (2040, 130)],
+                        lambda img, center: orc.forward_rgb8(img, center=center)[0])

@@ -427,3 +427,36 @@ def test_random_geometries_against_fp64_audit(lib):
     for i, (w, h) in enumerate(sizes):
         PC.check_product_against_audit64(lib, w, h, center=bool(i & 1), seed=100 + i, rel_bar=2.5e-4)
     PC.check_identity_roundtrip(lib, sizes)
+
+
+def test_dc_removal_option(lib):
+    """TFFT_DC_BIAS=128 against the device fp64 audit transform, BASELINE and odd sizes; and the batched
+    embed -> extract round trip (tile-resident extraction applies the same correction) still recovers every bit."""
+    import torch
+    audit = B.Context(64, 64, lib=lib)
+    PC.check_dc_removal(lib, [(512, 512), (1920, 1080), (2131, 1179), (3840, 2160), (600, 400)],
+                        lambda img, center: audit.audit_forward_rgb8_f64(img, center=center))
+    audit.close()
+    w, h, nimg, n = 2048, 1024, 8, 20000
+    imgs = np.stack([cover_rgb(w, h, 60 + i) for i in range(nimg)])
+    bits = np.random.default_rng(5).integers(0, 2, (nimg, n)).astype(np.uint8)
+    bins = B.Walk(bytes(range(32)), 1024, 2048, lib=lib).next(n)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev); d_bits = torch.from_numpy(bits).to(dev)
+    d_bins = torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()).to(dev)
+    d_out = torch.empty_like(d_img); d_raw = torch.zeros((nimg, n), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ber = {}
+    for mode in ("128", "0"):
+        os.environ["TFFT_DC_BIAS"] = mode
+        try:
+            ctx = B.Context(w, h, slots=nimg, lib=lib)
+        finally:
+            del os.environ["TFFT_DC_BIAS"]
+        ctx.embed_batch_dev(nimg, d_img.data_ptr(), w, h, d_bins.data_ptr(), d_bits.data_ptr(), n, d_out.data_ptr())
+        ctx.extract_batch_dev(nimg, d_out.data_ptr(), w, h, d_bins.data_ptr(), n, d_raw.data_ptr())
+        ctx.sync(); ctx.close()
+        ber[mode] = float((d_raw.cpu().numpy() != bits).mean())
+    # power-of-two cover: the raw bits come back up to the 8-bit rounding of the stego image (a few 1e-4, what Rep-7
+    # is for), with and without the option
+    assert ber["128"] < 1e-3 and abs(ber["128"] - ber["0"]) < 3e-4, ber
