@@ -73,7 +73,7 @@ struct tfft_ctx {
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     std::map<std::tuple<int, int, int, int>, float2*> dc;   // (valid, N, center, kind) -> DC-removal table, see get_dc_table
     float dc_bias = 0.0f;                 // TFFT_DC_BIAS=128: constant taken out of the pixels before the forward transform (accuracy
-                                          // option, see get_dc_table; costs ~4 % of the batch throughput, off by default)
+                                          // option, see get_dc_table; costs ~2 % of the batch throughput, off by default)
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)

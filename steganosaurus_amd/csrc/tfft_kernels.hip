@@ -571,7 +571,9 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 //   COLS_READ      extraction: nothing is stored at all -- the tile is parked in LDS and the bits of the bins
 //                  bucketed to it (P.rd_*) are read there (replaces the spectrum write + k_read's scattered reads)
 enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2 };
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN>
+// DC: the DC-removal epilogue (ColParams::dc_*) is compiled in; its own instantiation, because the kernel sits at the
+// 256-VGPR cap and even the unused code costs accumulation-register spills
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false>
 __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
     float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
-    if (P.dc_ah) {
+    if (DC) {
         for (int k = t * C + c; k < L; k += T * C) {
             const int row = P.out_a * k + P.out_b * g;
             lds_ah[k] = (g < P.G && row < P.PH) ? P.dc_ah[row] : make_float2(0.f, 0.f);
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
     // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
-    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (P.dc_ah && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     float2 W[tw_regs<L, E>()];
     fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
@@ -650,7 +652,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
             __syncthreads();            // the last gather of fft_block has been consumed by every thread
-            if (P.dc_ah) {
+            if (DC) {
 #pragma unroll
                 for (int m = 0; m < E; m++) u[m] = cadd(u[m], cmul(lds_ah[t + m * T], awc));
             }
@@ -685,7 +687,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
                 if (row < out_rows) {
                     float2 v = u[m];
                     if (P.tw_out) v = cmul(v, wo[m]);
-                    if (P.dc_ah) v = cadd(v, cmul(lds_ah[k], awc));
+                    if (DC) v = cadd(v, cmul(lds_ah[k], awc));
                     dst[(size_t)row * P.M] = v;
                 }
             }
@@ -1485,7 +1487,7 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
     return hipSuccess;
 }
 
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN>
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false>
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -1495,7 +1497,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (P.dc_ah ? (size_t)gpb * L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
-    auto k = k_fft_cols<LOGL, SIGN, MODE>;
+    auto k = k_fft_cols<LOGL, SIGN, MODE, DC>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1507,13 +1509,16 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
                        int n_planes, hipStream_t s) {
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
     if ((P.last_row_dev || P.rd_bins) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
+    if (P.dc_ah && sign < 0) return hipErrorInvalidValue;
+#define G(n, MODE)                                                                      \
+    (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
+             : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
 #define F(n)                                                                            \
     return sign < 0 ? launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s) \
-         : P.rd_bins ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_READ>(in, out, tw_ph, P, n_planes, s) \
-         : P.last_row_dev ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_ROWLIMIT>(in, out, tw_ph, P, n_planes, s) \
-                          : launch_cols_t<(n <= 10 ? n : 10), +1>(in, out, tw_ph, P, n_planes, s)
+         : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
+#undef G
     return hipSuccess;
 }
 
