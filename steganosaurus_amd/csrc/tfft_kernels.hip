@@ -573,7 +573,8 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2 };
 // DC: the DC-removal epilogue (ColParams::dc_*) is compiled in; its own instantiation, because the kernel sits at the
 // 256-VGPR cap and even the unused code costs accumulation-register spills
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false>
+// TW: the output twiddles of the two-step decomposition (P.tw_out) are compiled in: 32 VGPRs the final steps do not need
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false>
 __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -635,10 +636,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
     if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     float2 W[tw_regs<L, E>()];
     fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
-    float2 wo[E];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
-    if (P.tw_out) {
+    float2 wo[TW ? E : 1];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
+    if (TW) {
 #pragma unroll
-        for (int m = 0; m < E; m++) wo[m] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
+        for (int m = 0; m < E; m++) wo[TW ? m : 0] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
     }
     for (int tile = tile0; tile < tile1; tile++) {
         if (tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
@@ -686,7 +687,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
                 const int row = P.out_a * k + P.out_b * g;
                 if (row < out_rows) {
                     float2 v = u[m];
-                    if (P.tw_out) v = cmul(v, wo[m]);
+                    if (TW) v = cmul(v, wo[TW ? m : 0]);
                     if (DC) v = cadd(v, cmul(lds_ah[k], awc));
                     dst[(size_t)row * P.M] = v;
                 }
@@ -1487,7 +1488,7 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
     return hipSuccess;
 }
 
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false>
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false>
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
@@ -1497,7 +1498,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (P.dc_ah ? (size_t)gpb * L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
-    auto k = k_fft_cols<LOGL, SIGN, MODE, DC>;
+    auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1510,11 +1511,14 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
     if ((P.last_row_dev || P.rd_bins) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
     if (P.dc_ah && sign < 0) return hipErrorInvalidValue;
+    if (P.tw_out && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // the variants belong to final steps (no output twiddle)
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
              : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
 #define F(n)                                                                            \
-    return sign < 0 ? launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s) \
+    return sign < 0 ? (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
+                                : launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s)) \
+         : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
          : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F

@@ -25,12 +25,23 @@ def first(*names):
     return None
 
 
+def prefix(*prefixes):
+    """first kernel (template arguments after the prefix ignored: DC / TW switches) that has counters"""
+    for p in prefixes:
+        for name in S:
+            if name.startswith(p):
+                b = kib(name)
+                if b is not None:
+                    return b
+    return None
+
+
 stages = {
     "rows_fwd": first("k_rowcol_fwd<3>", "k_rows_fwd<11, 1>", "k_rows_fwd<12, 1>", "k_rows_fwd<10, 3>"),
     "rows_inv": first("k_colrow_inv<3>", "k_rows_inv<11, 1>", "k_rows_inv<12, 1>", "k_rows_inv<10, 3>"),
-    "cols_fwd_b": first(*["k_fft_cols<%d, 1, 0, %s>" % (l, d) for d in ("false", "true") for l in (8, 6, 7)]),
-    "cols_fwd_read": first(*["k_fft_cols<%d, 1, %d, %s>" % (l, m, d) for m in (2, 1) for d in ("false", "true") for l in (8, 6, 7)]),
-    "cols_inv_a": first(*["k_fft_cols<%d, -1, 0, false>" % l for l in (8, 6, 7)]),
+    "cols_fwd_b": prefix("k_fft_cols<8, 1, 0", "k_fft_cols<6, 1, 0", "k_fft_cols<7, 1, 0"),
+    "cols_fwd_read": prefix("k_fft_cols<8, 1, 2", "k_fft_cols<6, 1, 2", "k_fft_cols<7, 1, 2", "k_fft_cols<8, 1, 1", "k_fft_cols<6, 1, 1", "k_fft_cols<7, 1, 1"),
+    "cols_inv_a": prefix("k_fft_cols<8, -1, 0", "k_fft_cols<6, -1, 0", "k_fft_cols<7, -1, 0"),
     "embed": kib("k_embed"),
     "read": kib("k_read"),
     "capacity": first("k_capacity<false>", "k_capacity<true>"),
