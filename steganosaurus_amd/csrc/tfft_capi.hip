@@ -73,7 +73,7 @@ struct tfft_ctx {
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     std::map<std::tuple<int, int, int, int>, float2*> dc;   // (valid, N, center, kind) -> DC-removal table, see get_dc_table
     float dc_bias = 0.0f;                 // TFFT_DC_BIAS=128: constant taken out of the pixels before the forward transform (accuracy
-                                          // option, see get_dc_table; costs ~2 % of the batch throughput, off by default)
+                                          // option, see get_dc_table; both directions; costs ~3 % of the batch throughput, off by default)
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
@@ -211,9 +211,17 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
         case COLS_INV_A:
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
+                if (c->dc_bias != 0.0f) {
+                    rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
+                    rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
+                }
                 HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
                 cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
+                if (c->dc_bias != 0.0f) {
+                    rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
+                    rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
+                }
                 HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             }
             return TFFT_OK;
@@ -224,7 +232,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias};
             if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
             else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;

@@ -438,14 +438,14 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
         const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
         for (int m = t; m < (P.W >> 1); m += T) {
             const float2 v = lds[lay.idx(m, n1)];
-            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x);
-            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y);
+            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
+            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
         }
     } else {
         for (int n = t; n < P.W; n += T) {
             float v = ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)];
             if (P.center && ((n + y) & 1)) v = -v;
-            dst[3 * n] = (uint8_t)quantise_u8(v);
+            dst[3 * n] = (uint8_t)quantise_u8(v + P.bias);
         }
     }
 }
@@ -522,9 +522,10 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
             const int i0 = lay.idx(2 * g, 0), i1 = lay.idx(2 * g + 1, 0);
             const float2 r01 = lds[i0], r23 = lds[i1], g01 = lds[i0 + lay.pitch], g23 = lds[i1 + lay.pitch],
                          b01 = lds[i0 + 2 * lay.pitch], b23 = lds[i1 + 2 * lay.pitch];
-            const unsigned R0 = quantise_u8(s0 * r01.x), R1 = quantise_u8(s1 * r01.y), R2 = quantise_u8(s0 * r23.x), R3 = quantise_u8(s1 * r23.y);
-            const unsigned G0 = quantise_u8(s0 * g01.x), G1 = quantise_u8(s1 * g01.y), G2 = quantise_u8(s0 * g23.x), G3 = quantise_u8(s1 * g23.y);
-            const unsigned B0 = quantise_u8(s0 * b01.x), B1 = quantise_u8(s1 * b01.y), B2 = quantise_u8(s0 * b23.x), B3 = quantise_u8(s1 * b23.y);
+            const float bz = P.bias;      // DC removal: the constant taken out before the forward transform comes back here
+            const unsigned R0 = quantise_u8(s0 * r01.x + bz), R1 = quantise_u8(s1 * r01.y + bz), R2 = quantise_u8(s0 * r23.x + bz), R3 = quantise_u8(s1 * r23.y + bz);
+            const unsigned G0 = quantise_u8(s0 * g01.x + bz), G1 = quantise_u8(s1 * g01.y + bz), G2 = quantise_u8(s0 * g23.x + bz), G3 = quantise_u8(s1 * g23.y + bz);
+            const unsigned B0 = quantise_u8(s0 * b01.x + bz), B1 = quantise_u8(s1 * b01.y + bz), B2 = quantise_u8(s0 * b23.x + bz), B3 = quantise_u8(s1 * b23.y + bz);
             dstw[3 * g] = R0 | (G0 << 8) | (B0 << 16) | (R1 << 24);
             dstw[3 * g + 1] = G1 | (B1 << 8) | (R2 << 16) | (G2 << 24);
             dstw[3 * g + 2] = B2 | (R3 << 8) | (G3 << 16) | (B3 << 24);
@@ -534,7 +535,7 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
             const int n = off / 3, ch = off - 3 * n;
             float v = ldsf[2 * lay.idx(n >> 1, ch - plane0) + (n & 1)];
             if (P.center && ((n + y) & 1)) v = -v;
-            return quantise_u8(v);
+            return quantise_u8(v + P.bias);
         };
         if (PPB == 3) {
             const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
@@ -605,8 +606,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
     // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
     float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
     if (DC) {
-        for (int k = t * C + c; k < L; k += T * C) {
-            const int row = P.out_a * k + P.out_b * g;
+        for (int k = t * C + c; k < L; k += T * C) {       // forward: rows of the outputs; inverse: rows of the inputs
+            const int row = (SIGN > 0) ? P.out_a * k + P.out_b * g : P.in_a * k + P.in_b * g;
             lds_ah[k] = (g < P.G && row < P.PH) ? P.dc_ah[row] : make_float2(0.f, 0.f);
         }
         __syncthreads();
@@ -649,6 +650,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
             awc = awn;
             continue;
         }
+        if (DC && SIGN < 0) {           // first inverse step: the rank-1 term leaves before the transform (the row kernel adds c back)
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = csub(u[m], cmul(lds_ah[t + m * T], awc));
+        }
         fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* i
                 if (row < out_rows) {
                     float2 v = u[m];
                     if (TW) v = cmul(v, wo[TW ? m : 0]);
-                    if (DC) v = cadd(v, cmul(lds_ah[k], awc));
+                    if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
                     dst[(size_t)row * P.M] = v;
                 }
             }
@@ -1510,19 +1515,21 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
                        int n_planes, hipStream_t s) {
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
     if ((P.last_row_dev || P.rd_bins) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
-    if (P.dc_ah && sign < 0) return hipErrorInvalidValue;
-    if (P.tw_out && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // the variants belong to final steps (no output twiddle)
+    if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
              : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
+#define GI(n, DCF)                                                                      \
+    (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, true>(in, out, tw_ph, P, n_planes, s) \
+              : launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, false>(in, out, tw_ph, P, n_planes, s))
 #define F(n)                                                                            \
-    return sign < 0 ? (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
-                                : launch_cols_t<(n <= 10 ? n : 10), -1>(in, out, tw_ph, P, n_planes, s)) \
+    return sign < 0 ? (P.dc_ah ? GI(n, true) : GI(n, false)) \
          : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
          : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
 #undef G
+#undef GI
     return hipSuccess;
 }
 
