@@ -242,6 +242,15 @@ def main():
     raw = d_raw.cpu().numpy()
     ber = float((raw != bits).mean())
     usable_min = int(d_usable.min().item()) if not args.no_stats else None
+    if world > 1:
+        # over ALL ranks (untimed): wrong bits, bits, smallest capacity
+        acc = torch.tensor([float((raw != bits).sum()), float(raw.size)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        ber = float(acc[0].item() / acc[1].item())
+        if usable_min is not None:
+            um = torch.tensor([float(usable_min)], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(um, op=dist.ReduceOp.MIN)
+            usable_min = int(um.item())
 
     ms_step = elapsed / args.steps * 1e3
     pix_step_all = world * n_img * W * H
