@@ -72,8 +72,9 @@ struct tfft_ctx {
     uint64_t bit_index_n = 0;
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
     std::map<std::tuple<int, int, int, int>, float2*> dc;   // (valid, N, center, kind) -> DC-removal table, see get_dc_table
-    float dc_bias = 0.0f;                 // TFFT_DC_BIAS=128: constant taken out of the pixels before the forward transform (accuracy
-                                          // option, see get_dc_table; both directions; costs ~3 % of the batch throughput, off by default)
+    float dc_bias = 128.0f;               // constant taken out of the pixels before the forward transform and put back analytically (see
+                                          // get_dc_table; both directions).  ON by default: it is what keeps every coefficient within the
+                                          // 1e-4 relative tolerance on padded images.  TFFT_DC_BIAS=0 switches it off (A/B measurements only)
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
