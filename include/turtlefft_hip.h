@@ -96,8 +96,13 @@ int tfft_median_path(tfft_ctx* ctx, int slot, int fast[3]);
  * annulus [rmin,rmax]*min(PH,PW), off the axes, |F| >= thr[plane].  Synchronises. */
 int tfft_capacity(tfft_ctx* ctx, int slot, double rmin, double rmax, const double thr[3], uint64_t* usable);
 
-/* compute_cover_hash's magnitudes (S:428-436): |F[y][x]| for y,x < region of
- * each plane, out = 3*region*region doubles.  Synchronises. */
+/* compute_cover_hash's magnitudes (S:428-436): |F[y][x]| for y,x < region (<= 8) of
+ * each plane, out = 3*region*region doubles in plane, y, x order.  Evaluated in fp64
+ * straight from the image the slot's last tfft_forward_rgb8[_dev] call read (for the
+ * _dev variant that buffer must still be alive): 192 inner products, no transform,
+ * so the reference's quantiser floor(log(1+mag)/2) (S:433) sees its own values to
+ * ~1e-13 and the 32-byte cover hash is the reference's.  TFFT_E_STATE after a batch
+ * call (no single image belongs to the slot).  Synchronises. */
 int tfft_lowfreq_mag(tfft_ctx* ctx, int slot, int region, double* out);
 
 /* ------------------------------------------------------------- embed / read

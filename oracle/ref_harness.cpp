@@ -287,6 +287,34 @@ int64_t ref_deframe_bits(const char* pass, uint32_t iters, const uint8_t* bits, 
     return (int64_t)clen;
 }
 
+// compute_cover_hash (S:415-444) as do_embed / do_extract call it (S:1021-1033, S:1157-1169): on the
+// de-interleaved planes AFTER apply_center (S:914).  hash_out = the reference's own 32 bytes.  mags_out
+// (optional, 3*region*region doubles) = the magnitudes its lambda quantises, recomputed here with the
+// reference's pad_to_fft / fft2d / abs so that fixtures can carry them; q_out (optional) = their quantised
+// bytes.  Returns region = min(8, min(PH,PW)/8) (S:429).
+int ref_cover_hash(const uint8_t* rgb, int W, int H, int center, uint8_t hash_out[32], double* mags_out, uint8_t* q_out) {
+    vector<double> R, G, B;
+    to_planes_u8(rgb, W, H, 3, R, G, B);
+    apply_center(R, W, H, center != 0); apply_center(G, W, H, center != 0); apply_center(B, W, H, center != 0);
+    auto h = compute_cover_hash(R, G, B, W, H);
+    memcpy(hash_out, h.data(), 32);
+    int PW = 0, PH = 0, region = 0;
+    const vector<double>* planes[3] = {&R, &G, &B};
+    for (int p = 0; p < 3; p++) {
+        auto F = pad_to_fft(*planes[p], W, H, PW, PH);
+        fft2d(F, false);
+        region = min(8, min(PH, PW) / 8);
+        for (int y = 0; y < region; y++)
+            for (int x = 0; x < region; x++) {
+                double mag = abs(F[y][x]);
+                size_t i = ((size_t)p * region + y) * region + x;
+                if (mags_out) mags_out[i] = mag;
+                if (q_out) q_out[i] = (uint8_t)min(7.0, max(0.0, floor(log(1.0 + mag) / 2.0)));
+            }
+    }
+    return region;
+}
+
 // PNG I/O through the reference's vendored stb (S:909, S:1104) so fixtures and
 // the CLI agree on the container.
 int ref_png_write(const char* path, const uint8_t* rgb, int W, int H) {

@@ -243,6 +243,33 @@ void orc_forward_rgb8(const uint8_t* rgb, int W, int H, int center, double* out,
     free(F);
 }
 
+/* S:415-444 compute_cover_hash, as do_embed / do_extract call it (S:1021-1033, S:1157-1169: on the planes after
+ * apply_center): forward transform of each plane, |F[y][x]| for y, x < region = min(8, min(PH,PW)/8) (S:429),
+ * q = min(7, max(0, floor(log(1+mag)/2))) (S:433), SHA-256 over the 3*region^2 bytes in plane, y, x order.
+ * mags_out / q_out optional.  Returns region. */
+int orc_cover_hash(const uint8_t* rgb, int W, int H, int center, uint8_t hash_out[32], double* mags_out, uint8_t* q_out) {
+    int PW, PH; double* F = forward3(rgb, W, H, center, &PW, &PH);
+    size_t P = (size_t)PW * PH;
+    int region = imin(8, imin(PH, PW) / 8);
+    uint8_t q[192];
+    size_t n = 0;
+    for (int p = 0; p < 3; p++)
+        for (int y = 0; y < region; y++)
+            for (int x = 0; x < region; x++) {
+                const double* z = F + 2 * (p * P + (size_t)y * PW + x);
+                double mag = hypot(z[0], z[1]);
+                double v = floor(log(1.0 + mag) / 2.0);
+                if (v < 0.0) v = 0.0;
+                if (v > 7.0) v = 7.0;
+                if (mags_out) mags_out[n] = mag;
+                q[n++] = (uint8_t)v;
+            }
+    if (q_out) memcpy(q_out, q, n);
+    orc_sha256(q, n, hash_out);
+    free(F);
+    return region;
+}
+
 /* S:998-1008: per-plane count over the annulus with magnitude floor, c/2. */
 static uint64_t capacity_plane(const double* F, int PH, int PW, double rmin, double rmax, double t) {
     uint64_t c = 0; int mn = imin(PH, PW);

@@ -57,6 +57,11 @@ void tfh_turtle_subkeys(const uint8_t* secret, size_t n, uint8_t path_key_out[32
     turtle_subkeys(pk, sub);
 }
 
+// compute_cover_hash's quantiser + SHA-256 (S:433-443) over magnitudes from tfft_lowfreq_mag, and the path key it feeds
+// (S:1020-1040): secret = passphrase bytes or the 32-byte master key; cover_hash32 may be NULL
+void tfh_cover_hash_from_mags(const double* mags, size_t n, uint8_t out[32]) { const auto h = cover_hash_from_mags(mags, n); memcpy(out, h.data(), 32); }
+void tfh_path_key(const uint8_t* secret, size_t n, const uint8_t* cover_hash32, uint8_t out[32]) { const auto k = path_key_of(secret, n, cover_hash32); memcpy(out, k.data(), 32); }
+
 int tfh_png_write(const char* path, const uint8_t* rgb, int w, int h) { return png_write_rgb8(path, rgb, w, h) ? 0 : -1; }
 // two-call protocol: rgb == NULL returns the size through w,h
 int tfh_image_read(const char* path, uint8_t* rgb, uint64_t cap, int* w, int* h) {

@@ -5,6 +5,8 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <exception>
+
 namespace tfh {
 namespace {
 
@@ -80,6 +82,10 @@ bool png_decode_rgb8(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, int&
         const size_t ph = interlace ? (H > (uint32_t)ys[p] ? (H - ys[p] + dy[p] - 1) / dy[p] : 0) : H;
         if (pw && ph) total += ph * (1 + (pw * bits_pp + 7) / 8);
     }
+    // a deflate stream expands at most ~1032x: an IHDR that promises more than the IDAT bytes can hold is a forged
+    // (or truncated) file -- refuse it before sizing any buffer from its dimensions; and keep W*H*3 inside what this
+    // tool's transforms handle anyway (TFFT_MAX_DIM^2 pixels)
+    if (total > idat.size() * 1040 + 4096 || (uint64_t)W * H > (uint64_t)16384 * 16384) return false;
     std::vector<uint8_t> raw(total);
     uLongf dl = (uLongf)total;
     if (uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size()) != Z_OK || dl != total) return false;
@@ -117,7 +123,13 @@ bool png_decode_rgb8(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, int&
     return true;
 }
 
+static bool load_rgb8_unchecked(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h);
 bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h) {
+    // nothing may throw across the C entry points or out of the CLI's "Failed to load" path (bad_alloc / length_error
+    // from a hostile header)
+    try { return load_rgb8_unchecked(path, rgb, w, h); } catch (const std::exception&) { rgb.clear(); return false; }
+}
+static bool load_rgb8_unchecked(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     std::vector<uint8_t> data;
@@ -132,12 +144,12 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& 
             while (pos < data.size() && (data[pos] == ' ' || data[pos] == '\n' || data[pos] == '\r' || data[pos] == '\t')) pos++;
             if (pos < data.size() && data[pos] == '#') { while (pos < data.size() && data[pos] != '\n') pos++; continue; }
             long x = 0; bool any = false;
-            while (pos < data.size() && data[pos] >= '0' && data[pos] <= '9') { x = x * 10 + (data[pos] - '0'); pos++; any = true; }
+            while (pos < data.size() && data[pos] >= '0' && data[pos] <= '9') { x = x * 10 + (data[pos] - '0'); pos++; any = true; if (x > (1l << 30)) return false; }
             if (!any) return false;
             v[got++] = x;
         }
         pos++;
-        if (got < 3 || v[2] != 255 || v[0] < 1 || v[1] < 1) return false;
+        if (got < 3 || v[2] != 255 || v[0] < 1 || v[1] < 1 || v[0] > (1l << 24) || v[1] > (1l << 24)) return false;
         const int ch = data[1] == '6' ? 3 : 1;
         if (data.size() - pos < (size_t)v[0] * v[1] * ch) return false;
         w = (int)v[0]; h = (int)v[1];

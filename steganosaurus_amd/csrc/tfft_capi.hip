@@ -30,6 +30,7 @@ int ilog2i(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 struct Slot {     // geometry of one resident image; its buffers are slices of the context pools
     int W = 0, H = 0, PW = 0, PH = 0, PWi = 0, center = 0;
     bool has_spec = false;
+    const uint8_t* rgb_src = nullptr;     // device image the last single-image forward of this slot read (tfft_lowfreq_mag reads it again)
 };
 
 struct ColPlan { bool direct; int log_n1, log_n2; bool fused_fwd; };
@@ -248,7 +249,7 @@ int enqueue_forward(tfft_ctx* c, int s0, int n, const uint8_t* rgb_dev, hipStrea
         int rc = enqueue_fft_stage(c, s0, n, stage, rgb_dev, nullptr, st);
         if (rc) return rc;
     }
-    for (int i = 0; i < n; i++) c->slots[s0 + i].has_spec = true;
+    for (int i = 0; i < n; i++) { c->slots[s0 + i].has_spec = true; c->slots[s0 + i].rgb_src = nullptr; }
     return TFFT_OK;
 }
 
@@ -484,7 +485,9 @@ int tfft_forward_rgb8_dev(tfft_ctx* c, int slot, const void* rgb_dev, int w, int
     if (rc) return rc;
     if (pw) *pw = s.PW;
     if (ph) *ph = s.PH;
-    return enqueue_forward(c, slot, 1, (const uint8_t*)rgb_dev, c->stream);
+    rc = enqueue_forward(c, slot, 1, (const uint8_t*)rgb_dev, c->stream);
+    s.rgb_src = (const uint8_t*)rgb_dev;
+    return rc;
 }
 
 int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, int center, int* pw, int* ph) {
@@ -495,7 +498,9 @@ int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, i
     HIPCHK(c, hipMemcpyAsync(c->img(slot), rgb, (size_t)w * h * 3, hipMemcpyHostToDevice, c->stream));
     if (pw) *pw = s.PW;
     if (ph) *ph = s.PH;
-    return enqueue_forward(c, slot, 1, c->img(slot), c->stream);
+    rc = enqueue_forward(c, slot, 1, c->img(slot), c->stream);
+    s.rgb_src = c->img(slot);
+    return rc;
 }
 
 int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
@@ -538,15 +543,17 @@ int tfft_capacity(tfft_ctx* c, int slot, double rmin, double rmax, const double 
 }
 
 int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
-    if (!slot_ok(c, slot) || !out || region < 1) return TFFT_E_INVALID;
+    if (!slot_ok(c, slot) || !out || region < 1 || region > 8) return TFFT_E_INVALID;
     Slot& s = c->slots[slot];
-    if (!s.has_spec) return TFFT_E_STATE;
+    if (!s.has_spec || !s.rgb_src) return TFFT_E_STATE;
     if (region > s.PH || region > s.PW) return TFFT_E_INVALID;
-    const size_t bytes = (size_t)3 * region * region * sizeof(double);
-    if (bytes > (size_t)3 * s.PH * (s.PWi / 2) * sizeof(float2)) return TFFT_E_INVALID;
-    double* d = (double*)c->tmp(slot);     // tmp is free between forward and inverse
-    HIPCHK(c, launch_lowfreq(c->spec(slot), s.PH, s.PWi, region, d, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    // fp64 inner products with the image itself (k_lowfreq_*_f64): scratch = tmp, free between forward and inverse
+    const size_t row_bytes = (size_t)s.H * 3 * region * sizeof(double2), out_bytes = (size_t)3 * region * region * sizeof(double);
+    if (row_bytes + out_bytes > c->slot_stride * sizeof(float2)) return TFFT_E_INVALID;
+    double2* rowsum = (double2*)c->tmp(slot);
+    double* d = (double*)((char*)rowsum + row_bytes);
+    HIPCHK(c, launch_lowfreq_f64(s.rgb_src, s.W, s.H, s.PW, s.PH, s.center, region, rowsum, d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return TFFT_OK;
 }

@@ -132,6 +132,8 @@ hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, ui
 hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
                                  hipStream_t s);
 hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);
-hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s);
+// compute_cover_hash's low-frequency magnitudes in fp64 from the pixels (rowsum: H*3*region double2 of scratch)
+hipError_t launch_lowfreq_f64(const uint8_t* rgb, int W, int H, int PW, int PH, int center, int region, double2* rowsum, double* out,
+                              hipStream_t s);
 
 }  // namespace tfft

@@ -1358,12 +1358,58 @@ __global__ void k_export_full(const float2* __restrict__ spec, int PH, int PW, i
     const int p = (int)(e / ((size_t)PWout * PH));
     out[e] = full_bin(spec + (size_t)p * PH * (PW >> 1), y, x, PH, PW);
 }
-__global__ void k_lowfreq(const float2* __restrict__ spec, int PH, int PW, int region, double* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 3 * region * region) return;
-    const int x = e % region, y = (e / region) % region, p = e / (region * region);
-    const float2 v = full_bin(spec + (size_t)p * PH * (PW >> 1), y, x, PH, PW);
-    out[e] = hypot((double)v.x, (double)v.y);
+// compute_cover_hash's magnitudes (S:428-436) in fp64, straight from the pixels: |F[y][x]| for y, x < region <= 8 is a
+// 3 x region x region corner of the spectrum, i.e. 192 inner products with the image -- no transform needed, and fp64
+// keeps the quantiser floor(log(1+mag)/2) (S:433) on the reference's side of every bucket edge (the fp32 spectrum is
+// 1e-7..1e-6 off; these values agree with the reference's fp64 FFT to ~1e-13).
+//   rows: grid (H)  block (32, region)   rowsum[n][p][x] = sum_m s(m) pix[n][m][p] exp(+2 pi i x m/PW)
+//   cols: grid (3*region*region)  block 256   out[p][y][x] = | sum_n s(n) rowsum[n][p][x] exp(+2 pi i y n/PH) |
+__device__ __forceinline__ void unit_2pi(long long k, int N, double& c, double& s) {      // exp(2 pi i k/N), N a power of two
+    const double t = (double)(k & (long long)(N - 1)) / (double)N;                            // exact
+    sincos(6.283185307179586476925286766559 * t, &s, &c);
+}
+__global__ void k_lowfreq_rows_f64(const uint8_t* __restrict__ rgb, int W, int PW, int center, int region, double2* __restrict__ rowsum) {
+    double* red = reinterpret_cast<double*>(tfft_smem);                 // [region][32][6]
+    const int lane = threadIdx.x, x = threadIdx.y, n = blockIdx.x;
+    const uint8_t* row = rgb + (size_t)n * W * 3;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int m = lane; m < W; m += 32) {
+        double c, s; unit_2pi((long long)x * m, PW, c, s);
+        if (center && (m & 1)) { c = -c; s = -s; }
+#pragma unroll
+        for (int p = 0; p < 3; p++) { const double v = (double)row[3 * m + p]; acc[2 * p] += v * c; acc[2 * p + 1] += v * s; }
+    }
+    double* mine = red + ((size_t)x * 32 + lane) * 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) mine[i] = acc[i];
+    __syncthreads();
+    for (int d = 16; d >= 1; d >>= 1) {
+        if (lane < d) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) mine[i] += mine[d * 6 + i];
+        }
+        __syncthreads();
+    }
+    const double* tot = red + (size_t)x * 32 * 6;                        // lane 0's slot holds the sums of this x
+    if (lane < 3) rowsum[((size_t)n * 3 + lane) * region + x] = make_double2(tot[2 * lane], tot[2 * lane + 1]);
+}
+__global__ void k_lowfreq_cols_f64(const double2* __restrict__ rowsum, int H, int PH, int center, int region, double* __restrict__ out) {
+    double* red = reinterpret_cast<double*>(tfft_smem);                 // [256][2]
+    const int e = blockIdx.x, x = e % region, y = (e / region) % region, p = e / (region * region);
+    double re = 0, im = 0;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        double c, s; unit_2pi((long long)y * n, PH, c, s);
+        if (center && (n & 1)) { c = -c; s = -s; }
+        const double2 r = rowsum[((size_t)n * 3 + p) * region + x];
+        re += r.x * c - r.y * s; im += r.x * s + r.y * c;
+    }
+    red[2 * threadIdx.x] = re; red[2 * threadIdx.x + 1] = im;
+    __syncthreads();
+    for (int d = blockDim.x / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { red[2 * threadIdx.x] += red[2 * (threadIdx.x + d)]; red[2 * threadIdx.x + 1] += red[2 * (threadIdx.x + d) + 1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[e] = hypot(red[0], red[1]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1655,9 +1701,11 @@ hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, flo
     hipLaunchKernelGGL(k_export_full, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, spec, PH, PW, PWout, out);
     return hipGetLastError();
 }
-hipError_t launch_lowfreq(const float2* spec, int PH, int PW, int region, double* out, hipStream_t s) {
-    const int n = 3 * region * region;
-    hipLaunchKernelGGL(k_lowfreq, dim3((n + 255) / 256), dim3(256), 0, s, spec, PH, PW, region, out);
+hipError_t launch_lowfreq_f64(const uint8_t* rgb, int W, int H, int PW, int PH, int center, int region, double2* rowsum, double* out,
+                              hipStream_t s) {
+    if (region < 1 || region > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lowfreq_rows_f64, dim3(H), dim3(32, region), (size_t)region * 32 * 6 * sizeof(double), s, rgb, W, PW, center, region, rowsum);
+    hipLaunchKernelGGL(k_lowfreq_cols_f64, dim3(3 * region * region), dim3(256), 512 * sizeof(double), s, rowsum, H, PH, center, region, out);
     return hipGetLastError();
 }
 

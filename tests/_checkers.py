@@ -69,6 +69,7 @@ class Checker:
                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
             "extract_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_char_p, C.c_uint64,
                                        C.c_void_p]),
+            "cover_hash": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
         }
         if kind == "ref":
             sig.update({
@@ -172,6 +173,15 @@ class Checker:
         if rc != 0:
             raise RuntimeError("checker extract failed rc=%d" % rc)
         return out
+
+    def cover_hash(self, rgb, center=False):
+        """compute_cover_hash S:415-444 -> (region, hash32, magnitudes[3*region^2], quantised bytes)."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W = rgb.shape[:2]
+        h = np.zeros(32, np.uint8); mags = np.zeros(192, np.float64); q = np.zeros(192, np.uint8)
+        region = self._f["cover_hash"](_p(rgb), W, H, int(center), _p(h), _p(mags), _p(q))
+        n = 3 * region * region
+        return region, h.tobytes(), mags[:n].copy(), q[:n].copy()
 
     # -- oracle only -------------------------------------------------------------------
     def median_abs(self, plane):

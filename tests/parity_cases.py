@@ -418,3 +418,50 @@ def check_error_paths(lib):
         raise AssertionError("too large")
     except B.TfftError as e:
         assert e.status == -3
+
+
+def load_cover_hash_cases(golden_dir, max_pixels=None):
+    import json
+    with open(os.path.join(golden_dir, "cover_hash.json")) as f:
+        cases = json.load(f)["cases"]
+    return [c for c in cases if max_pixels is None or c["w"] * c["h"] <= max_pixels]
+
+
+def cover_of(case):
+    return cover_rgb(case["w"], case["h"], case["index"]) if case["cover"] == "lcg" else gradient_cover(case["w"], case["h"], case["index"])
+
+
+def host_cover_hash(host, mags):
+    """the CLI's quantiser + SHA-256 (tf_frame.cpp cover_hash_from_mags, S:433-443) through libtfhost.so"""
+    import ctypes as C
+    m = np.ascontiguousarray(mags, np.float64).ravel()
+    out = C.create_string_buffer(32)
+    host.tfh_cover_hash_from_mags(m.ctypes.data_as(C.c_void_p), C.c_size_t(m.size), out)
+    return out.raw
+
+
+def check_cover_hash(lib, host, golden_dir, max_pixels=None):
+    """(f-2) compute_cover_hash S:415-444: tfft_lowfreq_mag (fp64 inner products with the pixels) -> the CLI's
+    quantiser -> SHA-256 equals the REFERENCE's 32-byte hash on every fixture, including the covers whose
+    magnitudes sit 2e-7 / 4e-7 (relative) from a quantiser edge; magnitudes within 1e-11 of the reference's; and
+    they agree with the resident fp32 spectrum (same bins) to the transform's own accuracy."""
+    for c in load_cover_hash_cases(golden_dir, max_pixels):
+        img = cover_of(c)
+        ctx = B.Context(c["w"], c["h"], lib=lib)
+        pw, ph = ctx.forward_rgb8(img, c["center"])
+        region = min(8, min(ph, pw) // 8)
+        assert region == c["region"], c
+        if region == 0:
+            assert host_cover_hash(host, np.zeros(0)).hex() == c["hash"]
+            with pytest.raises(B.TfftError):
+                ctx.lowfreq_mag(1 if min(ph, pw) < 1 else 9)        # region out of range is refused
+            ctx.close()
+            continue
+        mags = ctx.lowfreq_mag(region)
+        want = np.array(c["mags"]).reshape(3, region, region)
+        assert np.all(np.abs(mags - want) <= 1e-11 * np.maximum(want, 1.0)), (c["w"], c["h"], np.abs(mags - want).max())
+        assert host_cover_hash(host, mags).hex() == c["hash"], (c["w"], c["h"], c["note"])
+        spec = np.abs(ctx.download_spectrum(pw, ph)[:, :region, :region].astype(np.complex128))
+        rms = np.sqrt(np.mean(want ** 2))
+        assert np.all(np.abs(spec - want) <= 1e-4 * want + 1e-5 * rms + 2 * 5.97e-8 * want.max()), (c["w"], c["h"])
+        ctx.close()

@@ -308,3 +308,9 @@ def test_dc_removal_option(emu, orc):
         PC.check_embed_extract(emu, orc, 128, 64, 500, dict(center=1), spectrum_bars=False)
     finally:
         del os.environ["TFFT_DC_BIAS"]
+
+
+def test_cover_hash_matches_the_reference(emu, golden_dir):
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(EMU_DIR), "..", "steganosaurus_amd", "libtfhost.so"))
+    PC.check_cover_hash(emu, host, golden_dir, max_pixels=300 * 300)

@@ -461,3 +461,10 @@ def test_dc_removal_option(lib):
     # power-of-two cover: the raw bits come back up to the 8-bit rounding of the stego image (a few 1e-4, what Rep-7
     # is for), with and without the option
     assert ber["128"] < 1e-3 and abs(ber["128"] - ber["0"]) < 3e-4, ber
+
+
+def test_cover_hash_matches_the_reference(lib, golden_dir):
+    """(f-2) every fixture of tests/golden/cover_hash.json, the 1080p and the quantisation-edge covers included."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(os.path.dirname(B.LIB_PATH), "libtfhost.so"))
+    PC.check_cover_hash(lib, host, golden_dir)

@@ -409,3 +409,19 @@ def test_bins_sort_orders_by_address_and_returns_the_walk_positions():
     b = np.zeros(6, S.BIN_DTYPE); b["x"] = [5, 3, 5, 3, 1, 5]; b["y"] = 7; b["plane"] = [1, 0, 1, 0, 2, 0]
     sb, idx = S.bins_sort(b)
     assert idx.tolist() == [1, 3, 5, 0, 2, 4]
+
+
+def test_cover_hash_quantiser_and_path_key(host, golden_dir):
+    """The CLI's half of compute_cover_hash (S:433-443) and the path key it feeds (S:1020-1033): quantiser + SHA-256 over
+    the reference's own magnitudes give the reference's hash; path_key = SHA256(secret || cover_hash)."""
+    import parity_cases as PC
+    for c in PC.load_cover_hash_cases(golden_dir):
+        assert PC.host_cover_hash(host, np.array(c["mags"])).hex() == c["hash"], (c["w"], c["h"])
+        q = np.minimum(7, np.maximum(0, np.floor(np.log(1.0 + np.array(c["mags"])) / 2.0))).astype(np.uint8)
+        assert q.tolist() == c["q"] and hashlib.sha256(q.tobytes()).hexdigest() == c["hash"]
+    ch = bytes.fromhex(PC.load_cover_hash_cases(golden_dir)[0]["hash"])
+    out = C.create_string_buffer(32)
+    host.tfh_path_key(b"test123", C.c_size_t(7), ch, out)
+    assert out.raw == hashlib.sha256(b"test123" + ch).digest()
+    host.tfh_path_key(b"test123", C.c_size_t(7), None, out)
+    assert out.raw == hashlib.sha256(b"test123").digest()

@@ -185,3 +185,33 @@ def test_against_live_reference(orc, ref):
             assert all(np.array_equal(x, y) for x, y in zip(eo, er))
             assert np.array_equal(orc.extract_bits(eo[0], pk, 150, P), ref.extract_bits(er[0], pk, 150, P))
         assert orc.capacity_rgb8(img)[0] == ref.capacity_rgb8(img)[0]
+
+
+def test_cover_hash_golden(orc, golden_dir):
+    """(f-2) compute_cover_hash S:415-444: region, magnitudes, quantised bytes and hash of the restatement equal the
+    reference-made fixture, quantisation-edge covers included (tests/gen_golden_coverhash.py)."""
+    import parity_cases as PC
+    cases = PC.load_cover_hash_cases(golden_dir)
+    assert len(cases) >= 12 and sum(1 for c in cases if "edge" in c["note"]) >= 2
+    assert min(c["edge_distance"] for c in cases if c["edge_distance"] is not None) < 1e-6
+    for c in cases:
+        if c["w"] * c["h"] > 1024 * 1024:
+            continue            # the 1080p case costs ~5 s of fp64 FFT: test_cover_hash_golden_1080p
+        region, h, mags, q = orc.cover_hash(PC.cover_of(c), c["center"])
+        assert region == c["region"] and h.hex() == c["hash"] and q.tolist() == c["q"], (c["w"], c["h"])
+        assert np.array_equal(mags, np.array(c["mags"])), (c["w"], c["h"])
+
+
+def test_cover_hash_golden_1080p(orc, golden_dir):
+    import parity_cases as PC
+    for c in PC.load_cover_hash_cases(golden_dir):
+        if c["w"] * c["h"] > 1024 * 1024:
+            region, h, mags, q = orc.cover_hash(PC.cover_of(c), c["center"])
+            assert (region, h.hex(), q.tolist()) == (c["region"], c["hash"], c["q"])
+
+
+def test_cover_hash_against_live_reference(orc, ref):
+    for (w, h, idx, center) in [(64, 64, 5, 0), (100, 30, 6, 1), (333, 200, 7, 0), (8, 8, 8, 1), (7, 300, 9, 0)]:
+        img = cover_rgb(w, h, idx)
+        a, b = orc.cover_hash(img, center), ref.cover_hash(img, center)
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), (w, h)
