@@ -176,6 +176,30 @@ int tfft_frame_expand_dev(tfft_ctx* ctx, int n_images, const void* header_dev, c
 int tfft_frame_majority_dev(tfft_ctx* ctx, int n_images, const void* bits_dev, uint64_t payload_len, void* header_out_dev,
                             void* payload_out_dev);
 
+/* The same two pipelines on PACKED BYTES, i.e. what do_embed / do_extract do around the walk (f-3 inside the
+ * pipelines: only 38 + payload_len bytes per image would have to cross PCIe):
+ *   embed  : header (38 B) and payload (ciphertext || tag, payload_len bytes) per image -> Rep-3 / Rep-7 stream
+ *            on the device (S:986-995) -> the first 912 + 56*payload_len positions of the caller's walk (n_bins
+ *            of them, n_bins >= that, else TFFT_E_INVALID) -> inverse.
+ *   extract: forward -> the raw bit of EVERY position of the caller's walk, read in the one pass that has the
+ *            spectrum on chip -> Rep-3 majority of the first 912 -> header bytes -> magic, version, clen ->
+ *            Rep-7 majority of the next 56*(clen+16) bits of the same walk (S:1223-1264).  The length comes out
+ *            of the image, not from the caller.
+ *            status_out[i] (int32) = clen >= 0, or -1 "Magic not found.", -2 "Unsupported version" (header byte 4
+ *            holds it), -3 the walk (n_bins) or the payload buffer (max_payload_len) is too short for what the
+ *            header announces (where the reference keeps walking, S:1260-1264).
+ *            header_out: 38 bytes per image (always written; the AAD of S:1299-1301).  payload_out: clen+16 bytes
+ *            per image at stride max_payload_len.  raw_bits_out (optional): the n_bins raw bits per image.
+ * n_bins is also the length a bit index (tfft_set_bit_index) must have been set for. */
+int tfft_embed_stream_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
+                                const void* bins_dev, uint64_t n_bins, const void* header_dev, const void* payload_dev,
+                                uint64_t payload_len, double alpha, double rmin, double rmax, double magmin,
+                                void* usable_out_dev, void* rgb_out_dev);
+int tfft_extract_stream_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
+                                  const void* bins_dev, uint64_t n_bins, double alpha, void* header_out_dev,
+                                  void* payload_out_dev, uint64_t max_payload_len, void* status_out_dev,
+                                  void* raw_bits_out_dev);
+
 /* The same two pipelines for HOST buffers (images packed back to back, one byte per bit): the slots
  * are split into two halves and three HIP streams overlap the PCIe copy-in of the next half-batch,
  * the kernels of the current one and the copy-out of the previous one.  The

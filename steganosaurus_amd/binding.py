@@ -54,6 +54,8 @@ SYMBOLS = {
     "tfft_extract_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
     "tfft_host_alloc": (_vp, [C.c_size_t]),
     "tfft_host_free": (None, [_vp]),
+    "tfft_embed_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
+    "tfft_extract_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp, _vp, _u64, _vp, _vp]),
     "tfft_walk_create": (_i, [C.c_char_p, _i, _i, _d, _d, _d, C.POINTER(_vp)]),
     "tfft_walk_next": (_i, [_vp, _u64, _vp, C.POINTER(_u64)]),
     "tfft_walk_start": (_i, [_vp, _pi, _pi, _pi]),
@@ -309,6 +311,18 @@ class Context:
     def extract_batch_dev(self, n_images, rgb_ptr, w, h, bins_ptr, n_bits, bits_out_ptr, alpha=0.5, center=False):
         _check(self.lib.tfft_extract_batch_dev(self.h, n_images, _ptr(rgb_ptr), w, h, int(center), _ptr(bins_ptr),
                                                n_bits, alpha, _ptr(bits_out_ptr)), "tfft_extract_batch_dev")
+
+    def embed_stream_batch_dev(self, n_images, rgb_ptr, w, h, bins_ptr, n_bins, header_ptr, payload_ptr, payload_len, out_ptr,
+                               alpha=0.5, center=False, rmin=0.05, rmax=0.45, magmin=0.01, usable_ptr=None):
+        _check(self.lib.tfft_embed_stream_batch_dev(self.h, n_images, _ptr(rgb_ptr), w, h, int(center), _ptr(bins_ptr), n_bins,
+                                                    _ptr(header_ptr), _ptr(payload_ptr), payload_len, alpha, rmin, rmax, magmin,
+                                                    _ptr(usable_ptr), _ptr(out_ptr)), "tfft_embed_stream_batch_dev")
+
+    def extract_stream_batch_dev(self, n_images, rgb_ptr, w, h, bins_ptr, n_bins, header_out_ptr, payload_out_ptr, max_payload_len,
+                                 status_out_ptr, raw_bits_out_ptr=None, alpha=0.5, center=False):
+        _check(self.lib.tfft_extract_stream_batch_dev(self.h, n_images, _ptr(rgb_ptr), w, h, int(center), _ptr(bins_ptr), n_bins, alpha,
+                                                      _ptr(header_out_ptr), _ptr(payload_out_ptr), max_payload_len, _ptr(status_out_ptr),
+                                                      _ptr(raw_bits_out_ptr)), "tfft_extract_stream_batch_dev")
 
     STAGES = ["rows_fwd", "cols_fwd_a", "cols_fwd_b", "embed", "cols_inv_a", "cols_inv_b", "rows_inv", "read",
               "medians", "capacity", "cols_fwd_read"]

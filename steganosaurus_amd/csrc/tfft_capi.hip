@@ -76,6 +76,7 @@ struct tfft_ctx {
     float dc_bias = 128.0f;               // constant taken out of the pixels before the forward transform and put back analytically (see
                                           // get_dc_table; both directions).  ON by default: it is what keeps every coefficient within the
                                           // 1e-4 relative tolerance on padded images.  TFFT_DC_BIAS=0 switches it off (A/B measurements only)
+    uint8_t* stream_bits = nullptr; unsigned* stream_plen = nullptr; size_t stream_cap = 0;   // tfft_*_stream_batch_dev: expanded / raw bits of a chunk
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;      // host-buffer pipeline (created on first use)
@@ -311,6 +312,7 @@ EmbedParams embed_params(const tfft_ctx* c, const Slot& s, uint64_t n, double al
     for (int i = 0; i < 3; i++) p.med[i] = med ? med[i] : 0.0;
     p.img_stride = c->slot_stride;
     p.bit_index = c->bit_index;            // callers check index_ok(c, n) first
+    p.limit = n;
     return p;
 }
 // a bit index, once set, must describe exactly the bin list it is used with
@@ -447,7 +449,7 @@ int tfft_destroy(tfft_ctx* c) {
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->dc) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
-    (void)hipFree(c->out_pool);
+    (void)hipFree(c->out_pool); (void)hipFree(c->stream_bits); (void)hipFree(c->stream_plen);
     for (int i = 0; i < 4; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -679,7 +681,7 @@ static int batch_geometry(tfft_ctx* c, int g, int w, int h, int center) {
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
-                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st) {
+                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull) {
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
@@ -692,6 +694,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)3 * s0 * TFFT_STAT_MAX_BLOCKS, usable, st));
     }
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+    if (limit < n_bits) ep.limit = limit;      // the stream is shorter than the bin list (image i's bits still n_bits apart)
     HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
     return enqueue_inverse(c, s0, g, rgb_out, st);
 }
@@ -827,6 +830,67 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
     return TFFT_OK;
 }
 
+// ---------------------------------------------------------------- packed-byte streams (SURVEY 8 f-3 wired into the pipelines)
+static int ensure_stream(tfft_ctx* c, uint64_t n_bins) {
+    const size_t need = (size_t)c->n_slots * n_bins;
+    if (need <= c->stream_cap && c->stream_plen) return TFFT_OK;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    (void)hipFree(c->stream_bits); c->stream_bits = nullptr; c->stream_cap = 0;
+    if (dev_alloc(c, (void**)&c->stream_bits, need + 64)) return TFFT_E_NOMEM;
+    c->stream_cap = need;
+    if (!c->stream_plen && dev_alloc(c, (void**)&c->stream_plen, (size_t)c->n_slots * sizeof(unsigned))) return TFFT_E_NOMEM;
+    return TFFT_OK;
+}
+
+int tfft_embed_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                uint64_t n_bins, const void* header_dev, const void* payload_dev, uint64_t payload_len, double alpha,
+                                double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || !bins_dev || !header_dev || (payload_len && !payload_dev)) return TFFT_E_INVALID;
+    const uint64_t n_bits = 38ull * 24 + payload_len * 56;           // S:986-995
+    if (n_bits > n_bins) return TFFT_E_INVALID;                      // the caller's walk is shorter than the stream
+    int rc = ensure_stream(c, n_bins);
+    if (rc) return rc;
+    const size_t img_bytes = (size_t)w * h * 3;
+    for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
+        const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
+        rc = batch_geometry(c, g, w, h, center);
+        if (rc) return rc;
+        // bits_from_bytes + rep3/rep7_encode on the device: image i's stream at stream_bits + i*n_bins
+        HIPCHK(c, launch_frame_expand((const uint8_t*)header_dev + (size_t)i0 * 38, (const uint8_t*)payload_dev + (size_t)i0 * payload_len, payload_len, g,
+                                      c->stream_bits, n_bins, c->stream));
+        rc = embed_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, c->stream_bits, n_bins, alpha, rmin, rmax,
+                         magmin, usable_out_dev ? (unsigned long long*)usable_out_dev + i0 : nullptr, (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes,
+                         c->stream, n_bits);
+        if (rc) return rc;
+    }
+    return TFFT_OK;
+}
+
+int tfft_extract_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                  uint64_t n_bins, double alpha, void* header_out_dev, void* payload_out_dev, uint64_t max_payload_len,
+                                  void* status_out_dev, void* raw_bits_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !bins_dev || n_bins == 0 || !header_out_dev || !status_out_dev || (max_payload_len && !payload_out_dev))
+        return TFFT_E_INVALID;
+    int rc = TFFT_OK;
+    if (!raw_bits_out_dev) { rc = ensure_stream(c, n_bins); if (rc) return rc; }
+    else if (!c->stream_plen && dev_alloc(c, (void**)&c->stream_plen, (size_t)c->n_slots * sizeof(unsigned))) return TFFT_E_NOMEM;
+    const size_t img_bytes = (size_t)w * h * 3;
+    for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
+        const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
+        rc = batch_geometry(c, g, w, h, center);
+        if (rc) return rc;
+        // every position of the caller's walk is read in the one pass that has the spectrum on chip; the header decides
+        // afterwards how many of them belong to the stream (S:1223-1264: 912 bits, clen, then 56*(clen+16) more)
+        uint8_t* raw = raw_bits_out_dev ? (uint8_t*)raw_bits_out_dev + (size_t)i0 * n_bins : c->stream_bits;
+        rc = extract_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, n_bins, alpha, raw, c->stream);
+        if (rc) return rc;
+        HIPCHK(c, launch_stream_decode(raw, n_bins, max_payload_len, g, (uint8_t*)header_out_dev + (size_t)i0 * 38,
+                                       (uint8_t*)payload_out_dev + (size_t)i0 * max_payload_len, (int*)status_out_dev + i0, c->stream_plen, c->stream));
+    }
+    return TFFT_OK;
+}
+
 // ---------------------------------------------------------------- host-buffer batches
 // The slots are split into a ring of up to four parts; while one part computes, the next parts' inputs
 // arrive over PCIe on a copy-in stream and earlier results leave on a copy-out stream.  Overlap needs pinned
@@ -916,7 +980,8 @@ int tfft_frame_expand_dev(tfft_ctx* c, int n_images, const void* header_dev, con
                           void* bits_out_dev) {
     if (!c || n_images < 0 || !header_dev || (payload_len && !payload_dev) || !bits_out_dev) return TFFT_E_INVALID;
     if (n_images == 0) return TFFT_OK;
-    HIPCHK(c, launch_frame_expand((const uint8_t*)header_dev, (const uint8_t*)payload_dev, payload_len, n_images, (uint8_t*)bits_out_dev, c->stream));
+    HIPCHK(c, launch_frame_expand((const uint8_t*)header_dev, (const uint8_t*)payload_dev, payload_len, n_images, (uint8_t*)bits_out_dev,
+                                  38ull * 24 + payload_len * 56, c->stream));
     return TFFT_OK;
 }
 int tfft_frame_majority_dev(tfft_ctx* c, int n_images, const void* bits_dev, uint64_t payload_len, void* header_out_dev,

@@ -60,6 +60,7 @@ struct EmbedParams {
     double med[3];
     size_t img_stride;     // float2 elements between images (grid.y = image)
     const uint32_t* bit_index;   // bins[i] carries stream bit bit_index[i] (nullptr: bit i); tfft_set_bit_index
+    uint64_t limit;              // embed only: stream bits >= limit are not written (the stream is shorter than the bin list)
 };
 
 struct CapParams {
@@ -128,9 +129,11 @@ int collect_bracket_resident_blocks();
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s);
 hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,
-                               hipStream_t s);
+                               uint64_t stride, hipStream_t s);      // image i's bits at bits + i*stride
 hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
                                  hipStream_t s);
+hipError_t launch_stream_decode(const uint8_t* bits, uint64_t n_bins, uint64_t max_plen, int n_images, uint8_t* header, uint8_t* payload,
+                                int* status, unsigned* plen, hipStream_t s);
 hipError_t launch_export_full(const float2* spec, int PH, int PW, int PWout, float2* out, hipStream_t s);
 // compute_cover_hash's low-frequency magnitudes in fp64 from the pixels (rowsum: H*3*region double2 of scratch)
 hipError_t launch_lowfreq_f64(const uint8_t* rgb, int W, int H, int PW, int PH, int center, int region, double2* rowsum, double* out,

@@ -761,6 +761,7 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     bits += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
     const uint64_t j = P.bit_index ? (uint64_t)P.bit_index[i] : i;      // the stream bit this bin carries
+    if (j >= P.limit) return;                // the stream ends before this position of the walk (tfft_embed_stream_batch_dev)
     const int x = bn.x, y = bn.y, p = bn.plane;
     if (p > 2 || x >= P.PW || y >= P.PH || x == 0 || y == 0 || 2 * x == P.PW || 2 * y == P.PH) {
         atomicOr(err, 1);     // outside the grid or on an excluded axis (S:698-700): never produced by the walk
@@ -1419,7 +1420,7 @@ __global__ void k_lowfreq_cols_f64(const double2* __restrict__ rowsum, int H, in
 //   expand  : grid (ceil(n_bits/256), n_images);  majority: grid (ceil((38+plen)/256), n_images)
 // ---------------------------------------------------------------------------
 __global__ void k_frame_expand(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t plen,
-                               uint8_t* __restrict__ bits) {
+                               uint8_t* __restrict__ bits, uint64_t stride) {
     const uint64_t n = 38ull * 24 + plen * 56;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1427,7 +1428,7 @@ __global__ void k_frame_expand(const uint8_t* __restrict__ header, const uint8_t
     uint64_t b; const uint8_t* src;
     if (i < 912) { b = i / 3; src = header + img * 38; }
     else { b = (i - 912) / 7; src = payload + img * plen; }
-    bits[img * n + i] = (uint8_t)((src[b >> 3] >> (7 - (b & 7))) & 1);
+    bits[img * stride + i] = (uint8_t)((src[b >> 3] >> (7 - (b & 7))) & 1);
 }
 __global__ void k_frame_majority(const uint8_t* __restrict__ bits, uint64_t plen, uint8_t* __restrict__ header,
                                  uint8_t* __restrict__ payload) {
@@ -1453,18 +1454,76 @@ __global__ void k_frame_majority(const uint8_t* __restrict__ bits, uint64_t plen
     }
 }
 
+// The extractor's two phases on the device (S:1223-1264): Rep-3 majority of the first 912 raw bits -> 38 header bytes ->
+// magic / version / clen -> how many bits of the SAME walk the payload takes; then Rep-7 majority of exactly those.
+//   status[img] = clen (>= 0) | -1 magic not found | -2 unsupported version | -3 the bin list (n_bins) or the payload
+//   buffer (max_plen) is too short for 912 + 56*(clen+16) bits (the reference would keep walking: S:1260-1264)
+//   plen[img]   = clen + 16 when status >= 0, else 0
+//   header: grid (n_images) block 64          payload: grid (ceil(max_plen/256), n_images) block 256
+__global__ void k_stream_header(const uint8_t* __restrict__ bits, uint64_t n_bins, uint64_t max_plen, uint8_t* __restrict__ header,
+                                int* __restrict__ status, unsigned* __restrict__ plen) {
+    uint8_t* hb = reinterpret_cast<uint8_t*>(tfft_smem);        // [38]
+    const uint64_t img = blockIdx.x;
+    const uint8_t* in = bits + img * n_bins;
+    const int j = threadIdx.x;
+    if (j < 38) {
+        unsigned v = 0;
+        if (n_bins >= 912) {
+            for (int q = 0; q < 8; q++) {
+                const uint8_t* p = in + (j * 8 + q) * 3;
+                v = (v << 1) | ((p[0] + p[1] + p[2]) >= 2 ? 1u : 0u);
+            }
+        }
+        hb[j] = (uint8_t)v;
+        header[img * 38 + j] = (uint8_t)v;
+    }
+    __syncthreads();
+    if (j == 0) {
+        int st; unsigned pl = 0;
+        if (n_bins < 912) st = -3;
+        else if (!(hb[0] == 'F' && hb[1] == 'T' && hb[2] == 'T' && hb[3] == 'G')) st = -1;      // S:1236
+        else if (hb[4] != 2) st = -2;                                                            // S:1237
+        else {
+            const unsigned long long clen = ((unsigned long long)hb[34] << 24) | ((unsigned long long)hb[35] << 16) | ((unsigned long long)hb[36] << 8) | hb[37];
+            const unsigned long long rest = clen + 16, need = 912ull + rest * 56ull;
+            if (need > n_bins || rest > max_plen) st = -3;
+            else { st = (int)clen; pl = (unsigned)rest; }
+        }
+        status[img] = st; plen[img] = pl;
+    }
+}
+__global__ void k_stream_payload(const uint8_t* __restrict__ bits, uint64_t n_bins, uint64_t max_plen, const unsigned* __restrict__ plen,
+                                 uint8_t* __restrict__ payload) {
+    const uint64_t img = blockIdx.y, k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= plen[img]) return;
+    const uint8_t* p = bits + img * n_bins + 912 + k * 56;
+    unsigned v = 0;
+    for (int q = 0; q < 8; q++, p += 7)
+        v = (v << 1) | ((p[0] + p[1] + p[2] + p[3] + p[4] + p[5] + p[6]) >= 4 ? 1u : 0u);
+    payload[img * max_plen + k] = (uint8_t)v;
+}
+
 // ===========================================================================
 // launchers
 // ===========================================================================
 hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,
-                               hipStream_t s) {
+                               uint64_t stride, hipStream_t s) {
     const uint64_t n = 38ull * 24 + plen * 56;
-    hipLaunchKernelGGL(k_frame_expand, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, header, payload, plen, bits);
+    if (stride < n) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_frame_expand, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, header, payload, plen, bits, stride);
     return hipGetLastError();
 }
 hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
                                  hipStream_t s) {
     hipLaunchKernelGGL(k_frame_majority, dim3((unsigned)((38 + plen + 255) / 256), n_images), dim3(256), 0, s, bits, plen, header, payload);
+    return hipGetLastError();
+}
+hipError_t launch_stream_decode(const uint8_t* bits, uint64_t n_bins, uint64_t max_plen, int n_images, uint8_t* header, uint8_t* payload,
+                                int* status, unsigned* plen, hipStream_t s) {
+    if (n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stream_header, dim3(n_images), dim3(64), 64, s, bits, n_bins, max_plen, header, status, plen);
+    if (max_plen)
+        hipLaunchKernelGGL(k_stream_payload, dim3((unsigned)((max_plen + 255) / 256), n_images), dim3(256), 0, s, bits, n_bins, max_plen, plen, payload);
     return hipGetLastError();
 }
 
