@@ -6,18 +6,22 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch of synthetic images that are
-already resident in HBM: embed (forward FFT x3 -> medians + capacity -> keyed phase
-embed -> inverse FFT x3 -> u8) followed by extract (forward FFT x3 -> keyed phase
-read) for every image of the per-GPU batch.  Images are independent, so ranks share
-nothing but the bin list (broadcast once over RCCL before the timed region):
-weak scaling, no collective on the data path.
+A "step" = one pass of the hot path over one batch of synthetic images that are already
+resident in HBM, from packed bytes to packed bytes like do_embed / do_extract:
+  embed   : header + payload bytes -> Rep-3/Rep-7 stream (device) -> forward FFT x3 -> medians + capacity
+            -> keyed phase embed -> inverse FFT x3 -> u8 stego
+  extract : stego -> forward FFT x3 -> raw bit of every position of the extractor's walk -> Rep-3 majority of the
+            first 912 -> header -> clen -> Rep-7 majority of the payload (the length comes out of the image)
+for every image of the per-GPU batch.  Images are independent, so ranks share nothing but the bin list
+(broadcast once over RCCL before the timed region): weak scaling, no collective on the data path.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: "roofline" (dominant kernel, HIP-event timed) and "cpu_baseline".
+Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" (dominant kernel, HIP-event
+timed, bytes = what the kernel has to move), "cpu_baseline" (+ parity of the GPU's image 0 against it) and
+"other_workloads" (the 4K batch the north_star target is phrased on, and 8192^2).
 """
 import argparse
 import hashlib
+import hmac
 import json
 import os
 import sys
@@ -33,14 +37,14 @@ WORKLOADS = {
     "1080p_batch": (1920, 1080, 4096, 32, "configs[3] shard: 32 x (1920x1080 RGB, 4 KB payload) per GPU = configs[1] geometry"),
     "1080p_single": (1920, 1080, 4096, 1, "configs[1]: single 1920x1080 RGB, 4 KB payload"),
     "4k_single": (3840, 2160, 32768, 1, "configs[2]: single 3840x2160 RGB, 32 KB payload"),
-    "4k_batch": (3840, 2160, 32768, 8, "8 x configs[2] (batched 4K UHD)"),
+    "4k_batch": (3840, 2160, 32768, 8, "8 x configs[2] (batched 4K UHD: the span north_star's >= 60 % target names)"),
     "8192_single": (8192, 8192, 131072, 1, "configs[4]: 8192x8192 RGB, 128 KB payload"),
     "512_single": (512, 512, 1024, 1, "configs[0]: 512x512 RGB, 1 KB secret"),
-    "1000p_batch": (1920, 1000, 4096, 32, "experiment: 1920x1000 pads to 2048x1024 (column length 1024)"),
-    "4kx500_batch": (3840, 500, 256, 32, "experiment: 3840x500 pads to 4096x512 (direct column length 512)"),
+    "2048_batch": (2048, 2048, 4096, 16, "pow2 companion of configs[1] (SURVEY 8d): full payload recovery asserted"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 C64 = 8                      # bytes per complex64 bin
+WALK_SLACK = 1.25            # the extractor does not know the length: its walk is this much longer than the stream
 
 
 def next_pow2(v):
@@ -50,29 +54,29 @@ def next_pow2(v):
     return p
 
 
-def model_bytes(w, h, n_bits):
-    """SURVEY.md 8(d) algorithmic byte model (full complex64 planes, two passes per 2-D FFT)."""
+def survey_model_bytes(w, h, n_bits):
+    """SURVEY.md 8(d) byte model (FULL complex64 planes, two passes per 2-D FFT).  Kept for reference only: this
+    implementation stores the Hermitian half spectrum, so dividing these bytes by time is NOT a fraction of peak."""
     P = next_pow2(w) * next_pow2(h)
     b_embed = 3 * (6 * P * C64 + 2 * w * h) + 40 * n_bits
     b_extract = 3 * (3 * P * C64 + w * h) + 16 * n_bits
     return b_embed, b_extract
 
 
-def fused_plan(w, h):
-    """k_rowcol_fwd / k_colrow_inv (rows fused with the adjacent length-8 column step) are used for
-    images that pad to 2048 columns and at least 128 rows (tfft_capi.hip plan_cols)."""
-    return max(2, next_pow2(w)) == 2048 and next_pow2(h) >= 128 and os.environ.get("TFFT_FUSE", "1") != "0"
-
-
-def kernel_bytes(stage, w, h, n_bits, two_step, read_rows_frac=1.0):
-    """Compulsory HBM bytes of each kernel in THIS implementation's layout (half spectrum,
-    rows >= H skipped where the data is known to be zero / not needed).  DESIGN.md section 4."""
+def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
+    """COMPULSORY HBM bytes of each kernel in this implementation's layout (Hermitian half spectrum of PH x PW/2 complex64 per
+    plane; rows >= H never stored or loaded where they are known to be zero / not needed).  These are the algorithmic bytes
+    `roofline.achieved` is computed from; rocprofv3 PMC traffic agrees with them within a few %."""
     PW, PH = max(2, next_pow2(w)), next_pow2(h)
     M = PW // 2
     plane_full = PH * M * C64
     plane_h = h * M * C64
     img = w * h
-    if fused_plan(w, h):
+    mn = min(PH, next_pow2(w))
+    bh = min(PH, int(0.45 * mn) + 1)
+    bw = min(M, int(0.45 * mn) + 1)
+    two_step = plan["two_step"]
+    if plan["fused"]:
         # fused kernels: u8 <-> full half-plane in one launch; the H x M intermediate never exists
         if stage == "rows_fwd":
             return 3 * img + 3 * plane_full
@@ -84,41 +88,231 @@ def kernel_bytes(stage, w, h, n_bits, two_step, read_rows_frac=1.0):
         "rows_fwd": 3 * img + 3 * plane_h,
         "cols_fwd_a": 3 * plane_h + 3 * plane_full,
         "cols_fwd_b": (6 * plane_full) if two_step else 0,
-        "embed": n_bits * (8 + 1 + 8 + 8),
+        "embed": n_bits * (8 + 1 + 8 + 8) + (n_bins - n_bits) * 12,
         "cols_inv_a": (6 * plane_full) if two_step else 3 * plane_full + 3 * plane_h,
         "cols_inv_b": (3 * plane_full + 3 * plane_h) if two_step else 0,
         "rows_inv": 3 * plane_h + 3 * img,
-        "read": n_bits * (8 + 8 + 1),
-        "medians": 3 * 3 * plane_full,
-        "capacity": 0,
-        # final forward column step of the extract path: reads everything and takes the bits out of its LDS-resident
-        # tiles (no spectrum store; TFFT_TILE_READ=0: stores the rows the bin list touches, then k_read)
-        "cols_fwd_read": int(3 * plane_full + (n_bits * (8 + 1) if read_rows_frac is None else 3 * plane_full * read_rows_frac)),
+        "read": n_bins * (8 + 8 + 1),
+        # one full read (bracket pass) + the 1/16-row sample; the candidate lists are a few 1e-3 of a plane
+        "medians": int(3 * plane_full * (1 + 1.0 / 16)),
+        # bounding box of the annulus: rows < bh, columns < bw of every plane
+        "capacity": 3 * bh * bw * C64,
+        # final forward column step of the extract path: reads everything, takes the bits out of its LDS-resident tiles
+        "cols_fwd_read": 3 * plane_full + n_bins * (8 + 1),
     }[stage]
 
 
-def algorithmic_bytes(stage, w, h, n_bits, two_step):
-    """SURVEY.md 8(d) ALGORITHMIC bytes of the pass a kernel implements (full complex64 planes, P = PW*PH
-    bins of 8 B, no credit for zero rows, the half spectrum or cache hits): row pass = W*H + P*c per
-    plane, column pass = 2*P*c per plane.  Where this implementation runs the column pass as two launches
-    each one is charged half of it; in the fused plan the fused kernel is charged the row pass only and
-    the remaining column launch the whole column pass."""
-    P = next_pow2(w) * next_pow2(h)
-    img = w * h
-    row = 3 * (img + P * C64)
-    col = 3 * 2 * P * C64
-    fused = fused_plan(w, h)
-    split = two_step and not fused
-    return {
-        "rows_fwd": row, "rows_inv": row,
-        "cols_fwd_a": 0 if fused else (col // 2 if split else col),
-        "cols_fwd_b": col if fused else (col // 2 if split else 0),
-        "cols_inv_a": col if fused else (col // 2 if split else col),
-        "cols_inv_b": 0 if fused else (col // 2 if split else 0),
-        "embed": 40 * n_bits, "read": 16 * n_bits,
-        "medians": 0, "capacity": 0,        # not in the 8(d) model: their time counts against the path fraction only
-        "cols_fwd_read": (col if fused else (col // 2 if split else col)) + 16 * n_bits,      # extraction's final forward column step (+ the gather it absorbs)
-    }[stage]
+def stream_header(clen):
+    """Header::to_bytes S:886-904 with the bench's fixed salt (bytes 0..15) and a zero nonce"""
+    return np.frombuffer(b"FTTG" + bytes([2, 0]) + bytes(range(16)) + bytes(12) + int(clen).to_bytes(4, "big"), np.uint8).copy()
+
+
+def rep_stream(header, payload):
+    return np.concatenate([np.repeat(np.unpackbits(header), 3), np.repeat(np.unpackbits(payload), 7)])
+
+
+class Workload:
+    """inputs resident in HBM + a context; step() = embed batch + extract batch"""
+
+    def __init__(self, name, torch, S, dev, local, rank, world, images=0, slots=0, stats=True, dist=None, backend="nccl", coll_dev=None):
+        self.name, self.torch, self.S, self.dev, self.rank, self.world, self.stats = name, torch, S, dev, rank, world, stats
+        W, H, secret, n_img, self.desc = WORKLOADS[name]
+        if images > 0:
+            n_img = images
+        self.W, self.H, self.secret, self.n_img = W, H, secret, n_img
+        from steganosaurus_amd.synth import cover_rgb, n_stream_bits
+        self.n_bits = n_stream_bits(secret)
+        self.plen = secret + 16
+        self.n_bins = int(self.n_bits * WALK_SLACK)
+        self.PW, self.PH = next_pow2(W), next_pow2(H)
+        n_bits, n_bins = self.n_bits, self.n_bins
+        covers = np.stack([cover_rgb(W, H, rank * n_img + i) for i in range(n_img)])
+        self.covers = covers
+        self.d_img = torch.from_numpy(covers).to(dev)
+        rng = np.random.default_rng(1234 + rank)
+        self.header = np.tile(stream_header(secret), (n_img, 1))
+        self.payload = rng.integers(0, 256, size=(n_img, self.plen), dtype=np.uint8)
+        self.d_header = torch.from_numpy(self.header).to(dev)
+        self.d_payload = torch.from_numpy(self.payload).to(dev)
+        self.d_bins = torch.empty((n_bins, 8), dtype=torch.uint8, device=dev)
+        d_index = torch.zeros(n_bins, dtype=torch.int64, device=dev)
+        self.sort_bins = os.environ.get("TFFT_BENCH_WALK_ORDER") != "1"      # "1": visit the bins in walk order (A/B knob)
+        self.t_walk = self.t_sort = 0.0
+        self.bins_walk = None
+        if rank == 0:
+            # host walk (sequential, content independent): computed once, shared by every image and rank
+            pk = hashlib.sha256(b"test123").digest()
+            key_walk = hmac.new(pk, b"turtle_keys" + b"\x01", hashlib.sha256).digest()     # HKDF-Expand first block (S:1054-1058)
+            t0 = time.time()
+            bins = S.Walk(key_walk, self.PH, self.PW).next(n_bins)
+            self.t_walk = time.time() - t0
+            self.bins_walk = bins
+            if self.sort_bins:
+                t0 = time.time()
+                bins, bit_index = S.bins_sort(bins)
+                self.t_sort = time.time() - t0
+                d_index.copy_(torch.from_numpy(bit_index.astype(np.int64)))
+            self.bins_used = bins
+            self.d_bins.copy_(torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()))
+        if world > 1:
+            # the only collective: 8 B x n_bins (+ the bit index) over xGMI, before the timed region
+            for tns in ((self.d_bins, d_index) if self.sort_bins else (self.d_bins,)):
+                if backend == "nccl":
+                    dist.broadcast(tns, src=0)
+                else:
+                    hb = tns.cpu()
+                    dist.broadcast(hb, src=0)
+                    tns.copy_(hb)
+        self.d_stego = torch.empty_like(self.d_img)
+        self.d_hdr_out = torch.zeros((n_img, 38), dtype=torch.uint8, device=dev)
+        self.d_pay_out = torch.zeros((n_img, self.plen), dtype=torch.uint8, device=dev)
+        self.d_status = torch.zeros(n_img, dtype=torch.int32, device=dev)
+        self.d_usable = torch.zeros(n_img, dtype=torch.int64, device=dev)
+        self.slots = max(1, min(slots if slots > 0 else 32, n_img))
+        self.ctx = S.Context(W, H, slots=self.slots, device=local)
+        self.plan = self.ctx.plan_info(W, H)          # which kernels this geometry takes (fused rows+columns, two-step columns)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if self.sort_bins:
+            self.ctx.set_bit_index(d_index.cpu().numpy().astype(np.uint32))
+
+    def embed(self, n=None):
+        n = n or self.n_img
+        self.ctx.embed_stream_batch_dev(n, self.d_img.data_ptr(), self.W, self.H, self.d_bins.data_ptr(), self.n_bins, self.d_header.data_ptr(),
+                                        self.d_payload.data_ptr(), self.plen, self.d_stego.data_ptr(),
+                                        usable_ptr=self.d_usable.data_ptr() if self.stats else None)
+
+    def extract(self, n=None, raw_ptr=None, src=None):
+        n = n or self.n_img
+        self.ctx.extract_stream_batch_dev(n, (src if src is not None else self.d_stego).data_ptr(), self.W, self.H, self.d_bins.data_ptr(), self.n_bins,
+                                          self.d_hdr_out.data_ptr(), self.d_pay_out.data_ptr(), self.plen, self.d_status.data_ptr(),
+                                          raw_bits_out_ptr=raw_ptr)
+
+    def step(self):
+        self.embed()
+        self.extract()
+
+    def close(self):
+        self.ctx.close()
+
+
+def timed(fn, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    return (time.perf_counter() - t0) / steps
+
+
+def path_bytes(wl, span):
+    """compulsory bytes of every kernel of the span ("roundtrip" | "embed"), per image"""
+    fwd = ["rows_fwd", "cols_fwd_a", "cols_fwd_b"]
+    e = fwd + (["medians", "capacity"] if wl.stats else []) + ["embed", "cols_inv_a", "cols_inv_b", "rows_inv"]
+    x = ["rows_fwd", "cols_fwd_a", "cols_fwd_read"] if wl.plan["two_step"] else ["rows_fwd", "cols_fwd_read"]
+    names = e if span == "embed" else e + x
+    return sum(kernel_bytes(s, wl.W, wl.H, wl.n_bits, wl.n_bins, wl.plan) for s in names)
+
+
+def profile_stages(wl, reps):
+    """per-kernel timing with HIP events on the stream the kernels run on (tfft_profile_stage): each stage is ONE batched launch
+    over the chunk of `slots` images, exactly as in the timed step"""
+    torch, S, ctx = wl.torch, wl.S, wl.ctx
+    slots = wl.slots
+    rng = np.random.default_rng(99)
+    d_bits = torch.from_numpy(rng.integers(0, 2, size=(slots, wl.n_bins), dtype=np.uint8)).to(wl.dev)
+    d_raw = torch.zeros((slots, wl.n_bins), dtype=torch.uint8, device=wl.dev)
+    ctx.forward_rgb8_dev(wl.d_img.data_ptr(), wl.W, wl.H)
+    ctx.sync()
+    stages = {}
+
+    def prof(sid, r):
+        return ctx.profile_stage(sid, r, wl.d_img.data_ptr(), wl.d_stego.data_ptr(), wl.d_bins.data_ptr(), d_bits.data_ptr(), d_raw.data_ptr(),
+                                 wl.n_bins, n_images=slots)
+    # the two-step column stages work in place, so repeating one of them destroys its input: time the forward stages first,
+    # rebuild a clean spectrum, then time everything that reads the spectrum, and the inverse stages last
+    for sid in [0, 1, 2, 10, "clean", 8, 9, 3, 7, 4, 5, 6]:
+        if sid == "clean":
+            for k in (0, 1, 2):
+                prof(k, 1)
+            continue
+        name = S.Context.STAGES[sid]
+        ms, nl = prof(sid, reps)
+        if nl == 0:
+            continue
+        nb = wl.n_bins          # the profiled embed / read launches cover every position of the walk
+        kb = kernel_bytes(name, wl.W, wl.H, nb, nb, wl.plan) * slots
+        stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots, "bytes": kb,
+                        "GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                        "frac": round(kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+        if wl.plan["fused"] and name in ("rows_fwd", "rows_inv"):
+            stages[name]["kernel"] = "rows + column step A fused" if name == "rows_fwd" else "column step B' + rows fused"
+    return stages
+
+
+def load_traffic(workload, stage):
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tf))
+        v = t.get(workload, {}).get(stage)
+        src = t.get("_source", {}).get(workload)
+        return v, src
+    except Exception:
+        return None, None
+
+
+def roofline_of(wl, stages, reps):
+    fft = {k: v for k, v in stages.items() if k.startswith(("rows", "cols"))}
+    dom = max(fft, key=lambda k: fft[k]["ms"])
+    d = stages[dom]
+    traffic, src = load_traffic(wl.name, dom)
+    sm_e, sm_x = survey_model_bytes(wl.W, wl.H, wl.n_bits)
+    return {"bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+            "traffic": traffic,
+            "traffic_source": (src or "profiles/traffic.json") + " -- rocprofv3 PMC of an earlier run of this same command, replayed, not measured in this run"
+            if traffic is not None else None,
+            "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"], "units_per_launch": d["images_per_launch"],
+            "how": "slowest FFT kernel of the step.  achieved = bytes the kernel has to move (Hermitian half spectrum, DESIGN.md section 4) x images "
+                   "per launch / mean launch time (HIP events on the launch stream, %d back-to-back launches); frac = achieved / 8 TB/s.  "
+                   "SURVEY 8(d)'s full-complex-plane model would credit about twice these bytes and is not reported as a fraction" % reps}
+
+
+def run_workload(wl, steps, warmup, barrier, reduce_max, with_stages, stage_reps, single_leg):
+    for _ in range(warmup):
+        wl.step()
+    dt = reduce_max(timed(wl.step, steps, barrier))
+    dte = reduce_max(timed(wl.embed, steps, barrier))
+    wl.ctx.sync()
+    pix = wl.n_img * wl.W * wl.H
+    b_rt, b_e = path_bytes(wl, "roundtrip"), path_bytes(wl, "embed")
+    res = {"value": round(wl.world * pix / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 4),
+           "path": {"roundtrip": {"bytes_per_image": b_rt, "GBs_per_gpu": round(b_rt * wl.n_img / dt / 1e9, 1),
+                                  "frac_of_peak": round(b_rt * wl.n_img / dt / 1e9 / HBM_PEAK_GBS, 4)},
+                    "embed_only": {"ms_per_step": round(dte * 1e3, 4), "MPixels_per_s": round(wl.world * pix / dte / 1e6, 1),
+                                   "bytes_per_image": b_e, "GBs_per_gpu": round(b_e * wl.n_img / dte / 1e9, 1),
+                                   "frac_of_peak": round(b_e * wl.n_img / dte / 1e9 / HBM_PEAK_GBS, 4)},
+                    "note": "compulsory HBM bytes of every kernel of the span (half-spectrum layout, statistics included) / wall time / 8 TB/s"}}
+    # ---- correctness inside the bench (untimed): the raw bits of the round trip, what the headers said, capacities
+    torch = wl.torch
+    d_raw = torch.zeros((wl.n_img, wl.n_bins), dtype=torch.uint8, device=wl.dev)
+    wl.extract(raw_ptr=d_raw.data_ptr())
+    wl.ctx.sync()
+    raw = d_raw.cpu().numpy()[:, :wl.n_bits]
+    want = np.stack([rep_stream(wl.header[i], wl.payload[i]) for i in range(wl.n_img)])
+    status = wl.d_status.cpu().numpy()
+    res["check"] = {"wrong_bits": int((raw != want).sum()), "bits": int(raw.size),
+                    "headers_decoded": int((status == wl.secret).sum()),
+                    "payloads_recovered": int(sum(status[i] == wl.secret and np.array_equal(wl.d_pay_out[i].cpu().numpy(), wl.payload[i]) for i in range(wl.n_img))),
+                    "images": wl.n_img, "min_capacity_bits": int(wl.d_usable.min().item()) if wl.stats else None}
+    if single_leg and wl.n_img > 1:
+        for _ in range(3):
+            wl.embed(1); wl.extract(1)
+        t1 = timed(lambda: (wl.embed(1), wl.extract(1)), 20, lambda: torch.cuda.synchronize())
+        res["single_image"] = {"value": round(wl.W * wl.H / t1 / 1e6, 1), "unit": "MPixels/s", "ms_per_image": round(t1 * 1e3, 4),
+                               "note": "one image per call, same context"}
+    if with_stages:
+        res["stages"] = profile_stages(wl, stage_reps)
+        res["roofline"] = roofline_of(wl, res["stages"], stage_reps)
+    return res
 
 
 def main():
@@ -131,8 +325,9 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="resident images per launch (default: the whole per-GPU batch, at most 32)")
     ap.add_argument("--no-stats", action="store_true", help="skip medians+capacity inside embed (not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the other_workloads legs (4k_batch, 8192_single)")
     ap.add_argument("--batched-only", action="store_true",
-                    help="profiling runs: skip the single-image and host-buffer legs so that every traced launch is a batched one")
+                    help="profiling runs: only the timed steps and the per-stage launches, so that every traced launch is a batched one")
     ap.add_argument("--stage-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -157,66 +352,8 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-
-    W, H, secret, n_img, wl_desc = WORKLOADS[args.workload]
-    if args.images > 0:
-        n_img = args.images
-    from steganosaurus_amd.synth import cover_rgb, n_stream_bits
-    n_bits = n_stream_bits(secret)
-    PW, PH = next_pow2(W), next_pow2(H)
-
-    # ---- inputs (untimed): synthetic covers resident in HBM, bit streams, the shared bin list
-    covers = np.stack([cover_rgb(W, H, rank * n_img + i) for i in range(n_img)])
-    d_img = torch.from_numpy(covers).to(dev)
-    rng = np.random.default_rng(1234 + rank)
-    bits = rng.integers(0, 2, size=(n_img, n_bits), dtype=np.uint8)
-    d_bits = torch.from_numpy(bits).to(dev)
-    d_bins = torch.empty((n_bits, 8), dtype=torch.uint8, device=dev)
-    d_index = torch.zeros(n_bits, dtype=torch.int64, device=dev)
-    sort_bins = os.environ.get("TFFT_BENCH_WALK_ORDER") != "1"       # "1": visit the bins in walk order (A/B knob)
-    t_walk = t_sort = 0.0
-    if rank == 0:
-        # host walk (sequential, content independent): computed once, shared by every image and rank
-        pk = hashlib.sha256(b"test123").digest()
-        import hmac
-        # HKDF-Expand(PRK=path_key, info="turtle_keys") first block = key_walk (S:1054-1058)
-        key_walk = hmac.new(pk, b"turtle_keys" + b"\x01", hashlib.sha256).digest()
-        t0 = time.time()
-        wk = S.Walk(key_walk, PH, PW)
-        bins = wk.next(n_bits)
-        t_walk = time.time() - t0
-        if sort_bins:
-            # address order for the device kernels (tfft_bins_sort); bits / results stay in stream order
-            t0 = time.time()
-            bins, bit_index = S.bins_sort(bins)
-            t_sort = time.time() - t0
-            d_index.copy_(torch.from_numpy(bit_index.astype(np.int64)))
-        d_bins.copy_(torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()))
-    if world > 1:
-        # the only collective: 8 B x n_bits over xGMI, before the timed region
-        for tns in ((d_bins, d_index) if sort_bins else (d_bins,)):
-            if backend == "nccl":
-                dist.broadcast(tns, src=0)
-            else:
-                hb = tns.cpu()
-                dist.broadcast(hb, src=0)
-                tns.copy_(hb)
-    d_stego = torch.empty_like(d_img)
-    d_raw = torch.empty((n_img, n_bits), dtype=torch.uint8, device=dev)
-    d_usable = torch.zeros(n_img, dtype=torch.int64, device=dev)
-
-    slots = max(1, min(args.slots if args.slots > 0 else 32, n_img))
-    ctx = S.Context(W, H, slots=slots, device=local)
-    stream = torch.cuda.Stream(device=dev)          # the context runs on this torch-visible HIP stream
+    stream = torch.cuda.Stream(device=dev)          # the contexts run on this torch-visible HIP stream
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-    if sort_bins:
-        ctx.set_bit_index(d_index.cpu().numpy().astype(np.uint32))
-
-    def step():
-        ctx.embed_batch_dev(n_img, d_img.data_ptr(), W, H, d_bins.data_ptr(), d_bits.data_ptr(), n_bits,
-                            d_stego.data_ptr(), usable_ptr=None if args.no_stats else d_usable.data_ptr())
-        ctx.extract_batch_dev(n_img, d_stego.data_ptr(), W, H, d_bins.data_ptr(), n_bits, d_raw.data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,218 +361,162 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ctx.sync()
+    def reduce_max(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
 
-    # ---- correctness inside the bench: every image has capacity, BER of the round trip is the reference's
-    raw = d_raw.cpu().numpy()
-    ber = float((raw != bits).mean())
-    usable_min = int(d_usable.min().item()) if not args.no_stats else None
+    wl = Workload(args.workload, torch, S, dev, local, rank, world, args.images, args.slots, not args.no_stats, dist, backend, coll_dev)
+    # every rank runs the same legs (timed steps, embed-only, correctness read); rank 0 alone adds the per-stage launches
+    res = run_workload(wl, args.steps, args.warmup, barrier, reduce_max, with_stages=(rank == 0), stage_reps=args.stage_reps,
+                       single_leg=(rank == 0 and not args.batched_only))
+    chk = res["check"]
     if world > 1:
-        # over ALL ranks (untimed): wrong bits, bits, smallest capacity
-        acc = torch.tensor([float((raw != bits).sum()), float(raw.size)], dtype=torch.float64, device=coll_dev)
+        acc = torch.tensor([float(chk["wrong_bits"]), float(chk["bits"]), float(chk["headers_decoded"]), float(chk["payloads_recovered"]),
+                            float(chk["images"])], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-        ber = float(acc[0].item() / acc[1].item())
-        if usable_min is not None:
-            um = torch.tensor([float(usable_min)], dtype=torch.float64, device=coll_dev)
+        chk["wrong_bits"], chk["bits"], chk["headers_decoded"], chk["payloads_recovered"], chk["images"] = (int(v) for v in acc.tolist())
+        if chk["min_capacity_bits"] is not None:
+            um = torch.tensor([float(chk["min_capacity_bits"])], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(um, op=dist.ReduceOp.MIN)
-            usable_min = int(um.item())
-
-    ms_step = elapsed / args.steps * 1e3
-    pix_step_all = world * n_img * W * H
-    value = pix_step_all / (elapsed / args.steps) / 1e6
-    b_embed, b_extract = model_bytes(W, H, n_bits)
+            chk["min_capacity_bits"] = int(um.item())
+    chk["roundtrip_ber"] = chk["wrong_bits"] / max(1, chk["bits"])
+    pow2 = (wl.PW, wl.PH) == (wl.W, wl.H)
+    chk["note"] = ("power-of-two cover: every header decodes and every payload byte comes back" if pow2 else
+                   "non-power-of-two cover: the REFERENCE does not round-trip these either (raw BER ~0.31, 'Magic not found.', SURVEY finding 1); "
+                   "parity with it is checked on image 0 under cpu_baseline.parity_vs_reference")
+    if pow2:
+        assert chk["payloads_recovered"] == chk["images"], chk
 
     out = {
         "metric": "MPixels/s embed+extract round-trip (RGB 2D-FFT fwd+inv)",
-        "value": round(value, 1), "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": res["value"], "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload, "describes": wl_desc, "image": [W, H], "padded": [PW, PH],
-                   "payload_bytes": secret, "n_bits": n_bits, "images_per_gpu": n_img, "images_per_launch": slots,
-                   "stats_in_embed": not args.no_stats, "parallelism": "independent images per rank, no data-path collective",
-                   "host_walk_s": round(t_walk, 3),
-                   "bin_order": "address order (tfft_bins_sort + tfft_set_bit_index)" if sort_bins else "walk order",
-                   "host_sort_s": round(t_sort, 3)},
-        "roundtrip_ber": ber, "min_capacity_bits": usable_min,
-        "path_model": {"bytes_per_image": b_embed + b_extract, "achieved_GBs": round((b_embed + b_extract) * n_img * world / (elapsed / args.steps) / 1e9 / world, 1),
-                       "frac_of_8TBs_per_gpu": round((b_embed + b_extract) * n_img / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                       "note": "SURVEY.md 8(d) byte model (full complex64 planes, 2 passes/FFT) over the whole step, per GPU"},
+        "config": {"workload": args.workload, "describes": wl.desc, "image": [wl.W, wl.H], "padded": [wl.PW, wl.PH],
+                   "payload_bytes": wl.secret, "stream_bits": wl.n_bits, "walk_positions": wl.n_bins,
+                   "images_per_gpu": wl.n_img, "images_per_launch": wl.slots, "stats_in_embed": wl.stats,
+                   "dc_removal": os.environ.get("TFFT_DC_BIAS", "128") != "0",
+                   "parallelism": "independent images per rank, no data-path collective",
+                   "host_walk_s": round(wl.t_walk, 3),
+                   "bin_order": "address order (tfft_bins_sort + tfft_set_bit_index)" if wl.sort_bins else "walk order",
+                   "host_sort_s": round(wl.t_sort, 3),
+                   "step": "packed bytes -> stego -> packed bytes: device framing, statistics, and the extractor learns the payload length from the header"},
+        "check": chk, "path": res["path"],
     }
-
-    # ---- embed only (forward + stats + embed + inverse): the span BASELINE.json's >= 60 % target is phrased on
-    def embed_only():
-        ctx.embed_batch_dev(n_img, d_img.data_ptr(), W, H, d_bins.data_ptr(), d_bits.data_ptr(), n_bits,
-                            d_stego.data_ptr(), usable_ptr=None if args.no_stats else d_usable.data_ptr())
-    embed_only()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        embed_only()
-    barrier()
-    dt_e = (time.perf_counter() - t0) / args.steps
-    if world > 1:
-        t = torch.tensor([dt_e], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_e = float(t.item())
-    out["path_model"]["embed_only"] = {"ms_per_step": round(dt_e * 1e3, 4), "bytes_per_image": b_embed,
-                                       "MPixels_per_s": round(world * n_img * W * H / dt_e / 1e6, 1),
-                                       "frac_of_8TBs_per_gpu": round(b_embed * n_img / dt_e / 1e9 / HBM_PEAK_GBS, 4)}
-
-    # ---- the same round trip on ONE image at a time (BASELINE configs[1] is phrased on a single image):
-    # launch/latency bound, reported beside the batched headline, never instead of it
-    single = None
-    if rank == 0 and n_img > 1 and not args.batched_only:
-        def one():
-            ctx.embed_batch_dev(1, d_img.data_ptr(), W, H, d_bins.data_ptr(), d_bits.data_ptr(), n_bits, d_stego.data_ptr(),
-                                usable_ptr=None if args.no_stats else d_usable.data_ptr())
-            ctx.extract_batch_dev(1, d_stego.data_ptr(), W, H, d_bins.data_ptr(), n_bits, d_raw.data_ptr())
-        for _ in range(3):
-            one()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            one()
-        torch.cuda.synchronize()
-        dt1 = (time.perf_counter() - t1) / 20
-        single = {"value": round(W * H / dt1 / 1e6, 1), "unit": "MPixels/s", "ms_per_image": round(dt1 * 1e3, 4),
-                  "note": "one image per call (24 kernel launches), same context"}
-    out["single_image"] = single
-
     if rank == 0:
-        # ---- per-kernel timing with HIP events on the stream the kernels run on (tfft_profile_stage):
-        # each stage is ONE batched launch over the chunk of `slots` images, exactly as in the timed step
-        ctx.forward_rgb8_dev(d_img.data_ptr(), W, H)
-        ctx.sync()
-        two_step = PH > (1 << int(os.environ.get("TFFT_COLS_DIRECT_MAX_LOG", "8")))
-        stages = {}
-
-        def prof(sid, reps):
-            return ctx.profile_stage(sid, reps, d_img.data_ptr(), d_stego.data_ptr(), d_bins.data_ptr(),
-                                     d_bits.data_ptr(), d_raw.data_ptr(), n_bits, n_images=slots)
-
-        # the two-step column stages work in place, so repeating one of them destroys its input: time the
-        # forward stages first, rebuild a clean spectrum, then time everything that reads the spectrum, and
-        # the inverse stages last
-        order = [0, 1, 2, 10, "clean", 8, 9, 3, 7, 4, 5, 6]
-        hb = bins if rank == 0 else None
-        last_row = int(np.where(hb["x"] <= PW // 2, hb["y"], (PH - hb["y"].astype(np.int64)) % PH).max())
-        rows_frac = None if os.environ.get("TFFT_TILE_READ", "1") != "0" else (last_row + 1) / PH
-        for sid in order:
-            if sid == "clean":
-                for k in (0, 1, 2):
-                    prof(k, 1)
-                continue
-            name = S.Context.STAGES[sid]
-            ms, nl = prof(sid, args.stage_reps)
-            if nl == 0:
-                continue
-            kb = kernel_bytes(name, W, H, n_bits, two_step, rows_frac) * slots
-            ab = algorithmic_bytes(name, W, H, n_bits, two_step) * slots
-            stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots,
-                            "algorithmic_bytes": ab, "algorithmic_GBs": round(ab / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
-                            "moved_bytes": kb, "moved_GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-            if fused_plan(W, H) and name in ("rows_fwd", "rows_inv"):
-                stages[name]["kernel"] = "k_rowcol_fwd (rows + column step A)" if name == "rows_fwd" else "k_colrow_inv (column step B' + rows)"
-        fft_stages = {k: v for k, v in stages.items() if k.startswith(("rows", "cols"))}
-        dom = max(fft_stages, key=lambda k: fft_stages[k]["ms"])
-        d = stages[dom]
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(d["algorithmic_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": d["algorithmic_bytes"], "avg_launch_ms": d["ms"],
-                           "moved_bytes_per_launch": d["moved_bytes"], "moved_GBs": d["moved_GBs"],
-                           "moved_frac": round(d["moved_GBs"] / HBM_PEAK_GBS, 4),
-                           "how": "the slowest FFT kernel of the step.  achieved = SURVEY.md 8(d) algorithmic bytes of the pass it "
-                                  "implements (full complex64 planes) x images per launch / mean launch time (HIP events on the "
-                                  "launch stream, %d back-to-back launches).  moved_* = the bytes the kernel really has to move in "
-                                  "this implementation's half-spectrum layout (DESIGN.md section 4): about half the model's, which "
-                                  "is why `achieved` can exceed what the HBM counters (`traffic`, bytes per launch) show" % args.stage_reps}
-        out["stages"] = stages
-
+        out["single_image"] = res.get("single_image")
+        out["roofline"] = res["roofline"]
+        out["stages"] = res["stages"]
         if world == 1 and not args.batched_only:
-            # side figure, never `value`: the same step when the caller hands over HOST buffers (pinned):
-            # tfft_embed_batch / tfft_extract_batch overlap the PCIe copies with the kernels on three streams
-            h_img = torch.from_numpy(covers).pin_memory()
-            h_bits = torch.from_numpy(bits).pin_memory()
-            h_stego = torch.empty(d_stego.shape, dtype=torch.uint8).pin_memory()
-            h_raw = torch.empty(d_raw.shape, dtype=torch.uint8).pin_memory()
-            h_us = torch.zeros(n_img, dtype=torch.int64).pin_memory()
-            lib, hnd = ctx.lib, ctx.h
-            import ctypes as C
-            def host_step():
-                rc = lib.tfft_embed_batch(hnd, n_img, C.c_void_p(h_img.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
-                                          C.c_void_p(h_bits.data_ptr()), n_bits, 0.5, 0.05, 0.45, 0.01,
-                                          None if args.no_stats else C.c_void_p(h_us.data_ptr()), C.c_void_p(h_stego.data_ptr()))
-                assert rc == 0, rc
-                rc = lib.tfft_extract_batch(hnd, n_img, C.c_void_p(h_stego.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
-                                            n_bits, 0.5, C.c_void_p(h_raw.data_ptr()))
-                assert rc == 0, rc
-            host_step()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                host_step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 3
-            same = bool((h_raw.numpy() == raw).all())
-            out["pcie_inclusive"] = {"value": round(n_img * W * H / dt / 1e6, 1), "unit": "MPixels/s", "ms_per_step": round(dt * 1e3, 3),
-                                     "with_cold_host_walk": round(n_img * W * H / (dt + t_walk + t_sort) / 1e6, 1),
-                                     "bits_identical_to_resident_run": same,
-                                     "note": "pinned host buffers through tfft_embed_batch/tfft_extract_batch: H2D of covers and bits, "
-                                             "kernels and D2H of stego/bits overlapped on three HIP streams (two half-batches in flight)"}
+            out["pcie_inclusive"] = pcie_leg(wl, torch)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, secret, n_bits, covers[0], bits[0])
+            out["cpu_baseline"] = cpu_baseline(wl, S)
+    wl.close()
+    if rank == 0 and world == 1 and not args.batched_only and not args.no_others and args.workload == "1080p_batch":
+        others = {}
+        for name in ("4k_batch", "8192_single"):
+            w2 = Workload(name, torch, S, dev, local, 0, 1, 0, 0, True)
+            r2 = run_workload(w2, 3, 1, barrier, reduce_max, with_stages=True, stage_reps=5, single_leg=False)
+            others[name] = {"describes": w2.desc, "value": r2["value"], "unit": "MPixels/s", "ms_per_step": r2["ms_per_step"], "steps": 3, "warmup": 1,
+                            "images_per_launch": w2.slots, "path": r2["path"], "check": r2["check"],
+                            "roofline": {k: r2["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic")},
+                            "stages_ms": {k: v["ms"] for k, v in r2["stages"].items()},
+                            "stages_frac": {k: v["frac"] for k, v in r2["stages"].items()}}
+            w2.close()
+        out["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.barrier()          # rank 0 did its extra per-kernel profiling while the others waited here
         dist.destroy_process_group()
 
 
-def cpu_baseline(W, H, secret, n_bits, cover, bits):
-    """The reference CPU path (oracle/_ref, the reference TU compiled in place) timed on this
-    host, one thread, one image of the same workload: embed + extract signal path, crypto/PNG
-    excluded.  Falls back to the repo's own restatement (kind "port") when _ref did not travel."""
+def pcie_leg(wl, torch):
+    """side figure, never `value`: the same work when the caller hands over HOST buffers (pinned): tfft_embed_batch /
+    tfft_extract_batch overlap the PCIe copies with the kernels on three streams (bit-level interface: one byte per bit)"""
+    import ctypes as C
+    n_img, W, H, n_bits = wl.n_img, wl.W, wl.H, wl.n_bits
+    bits = np.stack([rep_stream(wl.header[i], wl.payload[i]) for i in range(n_img)])
+    bins = np.ascontiguousarray(wl.bins_walk[:n_bits])
+    ctx = wl.S.Context(W, H, slots=wl.slots, device=wl.dev.index or 0)
+    h_img = torch.from_numpy(wl.covers).pin_memory()
+    h_bits = torch.from_numpy(bits).pin_memory()
+    h_stego = torch.empty(h_img.shape, dtype=torch.uint8).pin_memory()
+    h_raw = torch.empty(h_bits.shape, dtype=torch.uint8).pin_memory()
+    h_us = torch.zeros(n_img, dtype=torch.int64).pin_memory()
+    lib, hnd = ctx.lib, ctx.h
+
+    def host_step():
+        rc = lib.tfft_embed_batch(hnd, n_img, C.c_void_p(h_img.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
+                                  C.c_void_p(h_bits.data_ptr()), n_bits, 0.5, 0.05, 0.45, 0.01,
+                                  C.c_void_p(h_us.data_ptr()) if wl.stats else None, C.c_void_p(h_stego.data_ptr()))
+        assert rc == 0, rc
+        rc = lib.tfft_extract_batch(hnd, n_img, C.c_void_p(h_stego.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
+                                    n_bits, 0.5, C.c_void_p(h_raw.data_ptr()))
+        assert rc == 0, rc
+    host_step()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        host_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    same = bool((h_stego.numpy() == wl.d_stego.cpu().numpy()).all())
+    ctx.close()
+    return {"value": round(n_img * W * H / dt / 1e6, 1), "unit": "MPixels/s", "ms_per_step": round(dt * 1e3, 3),
+            "with_cold_host_walk": round(n_img * W * H / (dt + wl.t_walk + wl.t_sort) / 1e6, 1),
+            "stego_identical_to_resident_run": same,
+            "note": "pinned host buffers through tfft_embed_batch/tfft_extract_batch: H2D of covers and bits, kernels and D2H of stego/bits "
+                    "overlapped on three HIP streams"}
+
+
+def cpu_baseline(wl, S):
+    """The reference CPU path (oracle/_ref, the reference TU compiled in place) timed on this host, one thread, one image of the
+    same workload: embed + extract signal path, crypto/PNG excluded.  Falls back to the repo's own restatement (kind "port") when
+    _ref did not travel.  The same image then goes through the GPU path and is compared with what the reference produced."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _checkers import Checker, Params, have_ref
     kind = "reference" if have_ref() else "port"
     chk = Checker("ref" if kind == "reference" else "orc")
     pk = hashlib.sha256(b"test123").digest()
+    W, H = wl.W, wl.H
+    cover = wl.covers[0]
     # bound the sample to ~10-30 s: a 4K image costs ~60 s on the reference, so larger workloads
     # are sampled on a 1920x1080 crop of the same cover with the config-2 payload
     if W * H > 1920 * 1080:
         cover = np.ascontiguousarray(cover[:1080, :1920])
-        n = n_stream_bits_local(4096)
-        sample = "one 1920x1080 crop of the workload's cover, 4 KB payload (full image would exceed the 30 s bound)"
+        n = 38 * 24 + (4096 + 16) * 56
+        sample = "one 1920x1080 crop of the workload's cover, 4 KB payload (a full image would exceed the 30 s bound)"
     else:
-        n = n_bits
-        sample = "one image of the workload (%dx%d, %d stream bits)" % (W, H, n_bits)
-    b = np.ascontiguousarray(bits[:n])
+        n = wl.n_bits
+        sample = "one image of the workload (%dx%d, %d stream bits)" % (W, H, n)
+    b = np.ascontiguousarray(rep_stream(wl.header[0], wl.payload[0])[:n])
     t0 = time.perf_counter()
-    stego, _, _ = chk.embed_rgb8(cover, pk, b, Params())
+    stego, _, ref_bins = chk.embed_rgb8(cover, pk, b, Params(), want_bins=True)
     raw = chk.extract_bits(stego, pk, n, Params())
     dt = time.perf_counter() - t0
     h, w = cover.shape[:2]
     out = {"value": round(w * h / dt / 1e6, 4), "unit": "MPixels/s", "cores": 1, "kind": kind, "sample": sample,
-           "seconds": round(dt, 2), "ber": float((raw != b).mean()),
-           "host_cpus": os.cpu_count()}
+           "seconds": round(dt, 2), "ber": float((raw != b).mean()), "host_cpus": os.cpu_count()}
+    # ---- parity of the GPU path on the same image (untimed): same bins, stego within 1 LSB, raw bits of the reference's stego
+    key_walk = hmac.new(pk, b"turtle_keys" + b"\x01", hashlib.sha256).digest()
+    bins = S.Walk(key_walk, next_pow2(h), next_pow2(w)).next(n)
+    g = S.Context(w, h)
+    g.forward_rgb8(cover)
+    g.embed_bins(bins, b)
+    mine = g.inverse_rgb8(w, h)
+    g.forward_rgb8(stego)
+    got = g.read_bins(bins)
+    g.close()
+    d = mine.astype(np.int16) - stego
+    out["parity_vs_reference"] = {
+        "ok": bool(np.array_equal(S.bins_to_triples(bins), ref_bins) and np.abs(d).max() <= 1 and (d != 0).mean() < 0.01 and np.array_equal(got, raw)),
+        "bin_list_identical": bool(np.array_equal(S.bins_to_triples(bins), ref_bins)),
+        "stego_max_abs_diff": int(np.abs(d).max()), "stego_pixels_differing": int((d != 0).sum()), "pixels": int(d.size),
+        "raw_bits_of_reference_stego_mismatches": int((got != raw).sum()), "bits": int(n)}
+    assert out["parity_vs_reference"]["ok"], out["parity_vs_reference"]
     # SURVEY 8(d)(ii): the same image on every core of this GPU's host share at once (independent images are
     # how the path scales on a CPU too).  Threads, not processes: the checker is re-entrant C called through
     # ctypes (GIL released), and a GPU-initialised process must not exec children on this pool.
@@ -457,10 +538,6 @@ def cpu_baseline(W, H, secret, n_bits, cover, bits):
                             "seconds": round(dta, 2), "identical_results": bool(all((r == raw).all() for r in raws)),
                             "note": "one image per thread, %d threads at once" % ncore}
     return out
-
-
-def n_stream_bits_local(secret_len):
-    return 38 * 8 * 3 + (secret_len + 16) * 8 * 7
 
 
 if __name__ == "__main__":

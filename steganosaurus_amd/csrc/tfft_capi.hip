@@ -478,6 +478,16 @@ int tfft_sync(tfft_ctx* c) {
 }
 
 int tfft_last_hip_error(const tfft_ctx* c) { return c ? c->last_hip : 0; }
+
+int tfft_plan_info(const tfft_ctx* c, int w, int h, int info[4]) {
+    if (!c || !info || w < 1 || h < 1) return TFFT_E_INVALID;
+    int pw = next_pow2(w), ph = next_pow2(h);
+    if (pw < 2) pw = 2;
+    if (pw > TFFT_MAX_DIM || ph > TFFT_MAX_DIM) return TFFT_E_TOO_LARGE;
+    const ColPlan p = plan_cols(c, ph, pw);
+    info[0] = p.direct ? 1 : 0; info[1] = p.log_n1; info[2] = p.log_n2; info[3] = p.fused_fwd ? 1 : 0;
+    return TFFT_OK;
+}
 size_t tfft_device_bytes(const tfft_ctx* c) { return c ? c->dev_bytes : 0; }
 
 int tfft_forward_rgb8_dev(tfft_ctx* c, int slot, const void* rgb_dev, int w, int h, int center, int* pw, int* ph) {

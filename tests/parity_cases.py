@@ -465,3 +465,124 @@ def check_cover_hash(lib, host, golden_dir, max_pixels=None):
         rms = np.sqrt(np.mean(want ** 2))
         assert np.all(np.abs(spec - want) <= 1e-4 * want + 1e-5 * rms + 2 * 5.97e-8 * want.max()), (c["w"], c["h"])
         ctx.close()
+
+
+class HostBufs:
+    """device buffers of the emulated runtime are host arrays"""
+    @staticmethod
+    def put(a):
+        a = np.ascontiguousarray(a).copy()
+        return a, a.ctypes.data
+
+    @staticmethod
+    def get(h):
+        return h
+
+
+class TorchBufs:
+    """device buffers on cuda:0 through torch (plumbing only)"""
+    @staticmethod
+    def put(a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        torch.cuda.synchronize()
+        return t, t.data_ptr()
+
+    @staticmethod
+    def get(h):
+        return h.cpu().numpy()
+
+
+def make_header(clen, salt_seed=0, ver=2):
+    """Header::to_bytes S:886-904: FTTG, ver, flags=0, salt16, nonce12, clen_be32"""
+    rng = np.random.default_rng(1000 + salt_seed)
+    return np.frombuffer(b"FTTG" + bytes([ver, 0]) + rng.bytes(16) + rng.bytes(12) + int(clen).to_bytes(4, "big"), np.uint8).copy()
+
+
+def rep_stream(header, payload):
+    """bits_from_bytes + rep3 / rep7 (S:455-467, S:494-500, S:986-995) in numpy"""
+    return np.concatenate([np.repeat(np.unpackbits(header), 3), np.repeat(np.unpackbits(payload), 7)])
+
+
+def check_stream_batch(lib, orc, bufs, w, h, secrets=(40, 40, 40, 100, 100), slots=3, sort=True):
+    """tfft_embed_stream_batch_dev / tfft_extract_stream_batch_dev: packed header + payload bytes in, packed bytes out,
+    the length learnt from the image (S:1223-1264).  Power-of-two cover, so every byte comes back."""
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+    assert (ph, pw) == (h, w), "use a power-of-two cover: others do not round-trip in the reference either"
+    max_plen = max(secrets) + 16
+    n_bins = 912 + 56 * max_plen + 500                       # the extractor's walk: longer than any stream it will meet
+    bins = B.Walk(orc.subkeys(PK)[0], ph, pw, lib=lib).next(n_bins)
+    ctx = B.Context(w, h, slots=slots, lib=lib)
+    ubins = bins
+    if sort:
+        ubins, idx = B.bins_sort(bins, lib=lib)
+        ctx.set_bit_index(idx)
+    kb, pb = bufs.put(ubins.view(np.uint8).reshape(-1, 8))
+    rng = np.random.default_rng(77)
+    groups = {}
+    for i, sl in enumerate(secrets):
+        groups.setdefault(sl, []).append(i)
+    nimg = len(secrets)
+    covers = np.stack([cover_rgb(w, h, 50 + i) for i in range(nimg)])
+    headers = np.stack([make_header(sl, i) for i, sl in enumerate(secrets)])
+    payloads = [rng.integers(0, 256, sl + 16).astype(np.uint8) for sl in secrets]
+    stego = np.zeros_like(covers)
+    for sl, members in groups.items():                        # one embed call per payload length
+        plen = sl + 16
+        ci, cp = bufs.put(covers[members]); hi, hp = bufs.put(headers[members])
+        pi, pp = bufs.put(np.stack([payloads[m] for m in members])); oi, op = bufs.put(np.zeros_like(covers[members]))
+        ui, up = bufs.put(np.zeros(len(members), np.int64))
+        ctx.embed_stream_batch_dev(len(members), cp, w, h, pb, n_bins, hp, pp, plen, op, usable_ptr=up)
+        ctx.sync()
+        out = bufs.get(oi)
+        # == the bit-level call fed with the numpy expansion of the same bytes (bits beyond the stream: never written)
+        bits = np.zeros((len(members), n_bins), np.uint8)
+        for k, m in enumerate(members):
+            st = rep_stream(headers[m], payloads[m]); bits[k, :len(st)] = st
+        # positions >= the stream length must stay untouched: embed bit-level with a list cut to the stream length
+        n_bits = 912 + 56 * plen
+        c2 = B.Context(w, h, slots=slots, lib=lib)
+        cut = bins[:n_bits]
+        if sort:
+            cut, idx2 = B.bins_sort(cut, lib=lib); c2.set_bit_index(idx2)
+        k2, p2 = bufs.put(cut.view(np.uint8).reshape(-1, 8)); b2, bp2 = bufs.put(bits[:, :n_bits]); o2, op2 = bufs.put(np.zeros_like(covers[members]))
+        c2.embed_batch_dev(len(members), cp, w, h, p2, bp2, n_bits, op2)
+        c2.sync()
+        assert np.array_equal(bufs.get(o2), out), ("stream embed != bit-level embed", sl)
+        c2.close()
+        assert (bufs.get(ui) >= n_bits).all()
+        for k, m in enumerate(members):
+            stego[m] = out[k]
+    # one extraction call over images of different payload lengths + a plain cover + a future version + a too-long clen
+    bad_ver = stego[0].copy(); too_long = stego[0].copy()
+    c3 = B.Context(w, h, lib=lib)
+    for arr, hdr in ((bad_ver, make_header(secrets[0], 0, ver=3)), (too_long, make_header(10 ** 6, 0))):
+        st = rep_stream(hdr, payloads[0])
+        c3.forward_rgb8(covers[0]); c3.embed_bins(bins[:len(st)], st); arr[...] = c3.inverse_rgb8(w, h)
+    c3.close()
+    batch = np.concatenate([stego, covers[:1], bad_ver[None], too_long[None]])
+    nb = len(batch)
+    bi, bp = bufs.put(batch); ho, hop = bufs.put(np.zeros((nb, 38), np.uint8)); po, pop = bufs.put(np.zeros((nb, max_plen), np.uint8))
+    so, sop = bufs.put(np.zeros(nb, np.int32)); ro, rop = bufs.put(np.zeros((nb, n_bins), np.uint8))
+    ctx.extract_stream_batch_dev(nb, bp, w, h, pb, n_bins, hop, pop, max_plen, sop, raw_bits_out_ptr=rop)
+    ctx.sync()
+    status, hdr_out, pay_out, raw = bufs.get(so), bufs.get(ho), bufs.get(po), bufs.get(ro)
+    assert status[:nimg].tolist() == list(secrets), status
+    assert status[nimg:].tolist() == [-1, -2, -3], status
+    for i in range(nimg):
+        assert np.array_equal(hdr_out[i], headers[i]), i
+        assert np.array_equal(pay_out[i, :secrets[i] + 16], payloads[i]), i
+    assert hdr_out[nimg + 1][4] == 3
+    # raw bits == the bit-level extraction of the same batch; without raw_bits_out the decoded bytes are the same
+    r2, rp2 = bufs.put(np.zeros((nb, n_bins), np.uint8))
+    ctx.extract_batch_dev(nb, bp, w, h, pb, n_bins, rp2)
+    ctx.sync()
+    assert np.array_equal(bufs.get(r2), raw)
+    h3, hp3 = bufs.put(np.zeros((nb, 38), np.uint8)); p3, pp3 = bufs.put(np.zeros((nb, max_plen), np.uint8)); s3, sp3 = bufs.put(np.zeros(nb, np.int32))
+    ctx.extract_stream_batch_dev(nb, bp, w, h, pb, n_bins, hp3, pp3, max_plen, sp3)
+    ctx.sync()
+    assert np.array_equal(bufs.get(s3), status) and np.array_equal(bufs.get(h3), hdr_out) and np.array_equal(bufs.get(p3), pay_out)
+    # a walk shorter than the stream is refused at embed time; a walk shorter than what the header announces is status -3
+    with pytest.raises(B.TfftError):
+        ctx.embed_stream_batch_dev(1, bp, w, h, pb, n_bins, hop, pop, max_plen + 100, bp)
+    ctx.close()

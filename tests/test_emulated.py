@@ -314,3 +314,8 @@ def test_cover_hash_matches_the_reference(emu, golden_dir):
     import ctypes as C
     host = C.CDLL(os.path.join(os.path.dirname(EMU_DIR), "..", "steganosaurus_amd", "libtfhost.so"))
     PC.check_cover_hash(emu, host, golden_dir, max_pixels=300 * 300)
+
+
+def test_stream_batch_two_phase_extract(emu, orc):
+    PC.check_stream_batch(emu, orc, PC.HostBufs, 256, 256, secrets=(8, 8, 20, 20, 8), slots=3, sort=True)
+    PC.check_stream_batch(emu, orc, PC.HostBufs, 256, 128, secrets=(1,), slots=1, sort=False)

@@ -538,3 +538,12 @@ def test_batch_1080p_against_oracle(lib, orc):
         one.forward_rgb8(st)
         assert np.array_equal(one.read_bins(bins), raw[i]), i
     one.close()
+
+
+def test_stream_batch_two_phase_extract(lib, orc):
+    """(f-3 in the pipelines) packed bytes in, packed bytes out, length learnt from the header (S:1223-1264): chunks of < 8
+    images (spectrum + k_read) and of >= 8 (tile-resident read), 2048x2048 with the 4 KB payload among them."""
+    PC.check_stream_batch(lib, orc, PC.TorchBufs, 256, 256, secrets=(40, 40, 40, 100, 100), slots=3, sort=True)
+    PC.check_stream_batch(lib, orc, PC.TorchBufs, 512, 256, secrets=(64,) * 9 + (200,) * 2, slots=16, sort=True)
+    PC.check_stream_batch(lib, orc, PC.TorchBufs, 2048, 2048, secrets=(4096,) * 8, slots=12, sort=True)
+    PC.check_stream_batch(lib, orc, PC.TorchBufs, 256, 128, secrets=(1,), slots=1, sort=False)
