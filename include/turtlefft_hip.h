@@ -270,8 +270,10 @@ int tfft_timer_end(tfft_ctx* ctx, float* ms);
  * forward call (its geometry is reused for the whole batch; results of the
  * repeated stage are discarded by the caller).  Stages: 0 rows_fwd, 1 cols_fwd
  * step A (or the direct column pass), 2 cols_fwd step B, 3 embed, 4 cols_inv
- * step A, 5 cols_inv step B, 6 rows_inv, 7 read, 8 medians (7 launches),
- * 9 capacity (2 launches). */
+ * step A, 5 cols_inv step B, 6 rows_inv, 7 read, 8 medians (with the capacity
+ * count of the batch path inside its full pass), 9 capacity as a pass of its own
+ * (0 launches in the default configuration), 10 the final forward column step as
+ * extraction runs it. */
 int tfft_profile_stage(tfft_ctx* ctx, int n_images, int stage, int reps, const void* rgb_dev, void* rgb_out_dev,
                        const void* bins_dev, const void* bits_dev, void* bits_out_dev, uint64_t n_bits, double alpha,
                        float* ms_per_rep, int* n_launches);

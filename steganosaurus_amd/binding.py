@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libturtlefft_hip.so")
+# TFFT_LIB: an A/B build of the device library (csrc/Makefile `variant`); measurements only
+LIB_PATH = os.environ.get("TFFT_LIB") or os.path.join(_PKG, "libturtlefft_hip.so")
 
 TFFT_OK = 0
 STATUS = {0: "TFFT_OK", -1: "TFFT_E_INVALID", -2: "TFFT_E_NO_DEVICE", -3: "TFFT_E_TOO_LARGE", -4: "TFFT_E_NOMEM",

@@ -56,7 +56,8 @@ struct tfft_ctx {
     unsigned* cand_pool = nullptr;
     SelectState* sel = nullptr;           // [n_slots*3]
     float* med = nullptr;                 // [n_slots*3]
-    unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS]
+    unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS + n_slots]
+    float* amb = nullptr;                 // [n_slots*3*TFFT_AMB_CAP] |F|^2 of the bins the bracket pass could not decide
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
@@ -86,6 +87,7 @@ struct tfft_ctx {
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
     int median_force_fallback = 0;
+    int stats_fused = 1;                  // TFFT_STATS_FUSED=0: capacity as its own pass after the medians (A/B)
     int fuse = 1;
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
@@ -333,10 +335,15 @@ CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax)
     return p;
 }
 
-int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st) {
+// medians of slots [s0, s0+n); cap != nullptr: also their capacities (S:998-1008 with thr = magmin * median) -> usable[0..n)
+int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap = nullptr, unsigned long long* usable = nullptr) {
     const Slot& s = c->slots[s0];
+    // the batch capacity keeps its partial counts and flags in ONE region per call: slots [s0, s0+n) use the start of the pool's
+    // share of the compute stream (s0 is 0 or the second half of a two-stream chunk: shares do not overlap for n <= n_slots - s0)
+    unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
-                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st));
+                             c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st,
+                             cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable));
     return TFFT_OK;
 }
 
@@ -411,6 +418,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_FUSED")) c->stats_fused = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
@@ -428,7 +436,8 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
-    if (!rc) rc = dev_alloc(c, (void**)&c->partial, ns * 3 * TFFT_STAT_MAX_BLOCKS * sizeof(unsigned));
+    if (!rc) rc = dev_alloc(c, (void**)&c->partial, (ns * 3 * TFFT_STAT_MAX_BLOCKS + ns) * sizeof(unsigned));      // + one flag per image (batch capacity)
+    if (!rc) rc = dev_alloc(c, (void**)&c->amb, ns * 3 * TFFT_AMB_CAP * sizeof(float));
     if (!rc) rc = dev_alloc(c, (void**)&c->usable, ns * sizeof(unsigned long long));
     if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
     if (!rc) rc = dev_alloc(c, (void**)&c->last_row, 2 * sizeof(int));
@@ -444,7 +453,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->dc) (void)hipFree(kv.second);
@@ -696,12 +705,17 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
     if (rc) return rc;
-    if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip
-        rc = enqueue_medians(c, s0, g, st);
-        if (rc) return rc;
+    if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip: capacity is counted inside the median's full pass
         CapParams p = cap_params(c, s, rmin, rmax);
         p.magmin = magmin;
-        HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)3 * s0 * TFFT_STAT_MAX_BLOCKS, usable, st));
+        if (c->stats_fused && p.bw > 0) {
+            rc = enqueue_medians(c, s0, g, st, &p, usable);
+            if (rc) return rc;
+        } else {
+            rc = enqueue_medians(c, s0, g, st);
+            if (rc) return rc;
+            HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), usable, st));
+        }
     }
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
     if (limit < n_bits) ep.limit = limit;      // the stream is shorter than the bin list (image i's bits still n_bits apart)
@@ -1013,8 +1027,8 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
-    if (stage == MEDIANS) launches = c->median_force_fallback ? 7 : 13;
-    if (stage == CAPACITY) launches = 2;
+    if (stage == MEDIANS) launches = (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);      // fused: + settle + the guarded recount
+    if (stage == CAPACITY) launches = c->stats_fused ? 0 : 2;      // fused: counted inside the medians' full pass
     const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
@@ -1055,7 +1069,13 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
                 HIPCHK(c, launch_read(c->spec(0), (const tfft_bin*)bins_dev, nullptr, ep, n_images, (uint8_t*)bits_out_dev, c->err, c->stream));
                 break;
             }
-            case MEDIANS: rc = enqueue_medians(c, 0, n_images, c->stream); break;
+            case MEDIANS:
+                if (c->stats_fused) {
+                    CapParams p = cap_params(c, s, 0.05, 0.45);
+                    p.magmin = 0.01;
+                    rc = enqueue_medians(c, 0, n_images, c->stream, &p, c->usable);
+                } else rc = enqueue_medians(c, 0, n_images, c->stream);
+                break;
             case CAPACITY: {
                 CapParams p = cap_params(c, s, 0.05, 0.45);
                 p.magmin = 0.01;

@@ -99,8 +99,15 @@ struct SelectState {        // one per (image, plane)
     unsigned n_cand;
     unsigned lo, hi;            // fast path: bracket of level-1 buckets around the sample median
     unsigned done;              // 0 open / fallback needed, 2 fast path verified at level 2, 1 median written
-    unsigned pad;
+    unsigned fast;              // 1: the median came from the fast path (set with done = 1 by k_select_fast<3>)
+    // capacity counted inside the bracket pass (batch path): the threshold T2 = mag2_threshold(magmin * median) is only
+    // known afterwards, but the bracket pins it to [t2_lo, t2_hi]: bins at or above t2_hi count now, bins below t2_lo
+    // never, the few in between are parked (their |F|^2, once per full-grid bin) and settled by k_capacity_settle
+    float t2_lo, t2_hi;
+    unsigned n_amb;             // parked values (may exceed TFFT_AMB_CAP: then the plane falls back to k_capacity)
+    unsigned cap_pad;
 };
+#define TFFT_AMB_CAP 8192
 
 hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s);
@@ -123,11 +130,14 @@ hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits,
                         const EmbedParams& P, int n_images, int* err, hipStream_t s);
 hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* jitter, const EmbedParams& P,
                        int n_images, uint8_t* bits_out, int* err, hipStream_t s);
+// cap != nullptr: also S:998-1008 for every image (magmin in cap->magmin), counted inside the full median pass:
+// partial = [n_images*3*TFFT_STAT_MAX_BLOCKS] block counts, amb = [n_images*3*TFFT_AMB_CAP] parked |F|^2, usable[n_images]
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
-                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident, hipStream_t s);
+                          unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident, hipStream_t s,
+                          const CapParams* cap = nullptr, unsigned* partial = nullptr, float* amb = nullptr, unsigned long long* usable = nullptr);
 int collect_bracket_resident_blocks();
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
-                           unsigned* partial, unsigned long long* usable, hipStream_t s);
+                           unsigned* partial, unsigned long long* usable, hipStream_t s, const unsigned* only_flagged = nullptr);
 hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, uint64_t plen, int n_images, uint8_t* bits,
                                uint64_t stride, hipStream_t s);      // image i's bits at bits + i*stride
 hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,

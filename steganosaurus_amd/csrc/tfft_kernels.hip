@@ -29,6 +29,12 @@
 #ifndef TFFT_WAVES_PER_EU
 #define TFFT_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
+// column kernels of 16 elements per thread: occupancy floor handed to the register allocator.  Measured (round 2, A/B on one
+// box): 2 (<= 256 registers, two workgroups per CU) buys NOTHING where it fits (final forward step 0.653 vs 0.646 ms) and
+// doubles the run time of the variants that then spill to scratch (output-twiddle steps 0.94 / 1.19 vs 0.50 / 0.64 ms), so 1.
+#ifndef TFFT_COLS_WAVES
+#define TFFT_COLS_WAVES(logl) 1
+#endif
 #ifndef TFFT_ROWS_LAZY_LOG
 #define TFFT_ROWS_LAZY_LOG 11
 #endif
@@ -576,7 +582,7 @@ enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2 };
 // 256-VGPR cap and even the unused code costs accumulation-register spills
 // TW: the output twiddles of the two-step decomposition (P.tw_out) are compiled in: 32 VGPRs the final steps do not need
 template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false>
-__global__ void __launch_bounds__(cols_threads(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
+__global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COLS_WAVES(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
@@ -1036,11 +1042,11 @@ __device__ __forceinline__ unsigned long long stage_hist(const SelectState* s, u
 __global__ void k_select_init(SelectState* __restrict__ st, unsigned long long rank) {
     SelectState* s = st + blockIdx.x;
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) s->hist[i] = 0;
-    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->lo = 0; s->hi = 0; }
+    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->lo = 0; s->hi = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f; }
 }
 
 // ---- fast path ----------------------------------------------------------------------------------
-__global__ void k_select_guess(SelectState* __restrict__ st) {
+__global__ void k_select_guess(SelectState* __restrict__ st, double magmin) {
     unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
     SelectState* s = st + blockIdx.x;
     stage_hist(s, h, 4096);
@@ -1052,7 +1058,17 @@ __global__ void k_select_guess(SelectState* __restrict__ st) {
     __syncthreads();
     int b; unsigned long long before;
     find_bucket(h, p1, p2, total / 2, 4096, b, before);
-    if (threadIdx.x == 0) { s->lo = (unsigned)(b > 0 ? b - 1 : 0); s->hi = (unsigned)(b < 4095 ? b + 1 : 4095); }
+    if (threadIdx.x == 0) {
+        const unsigned lo = (unsigned)(b > 0 ? b - 1 : 0), hi = (unsigned)(b < 4095 ? b + 1 : 4095);
+        s->lo = lo; s->hi = hi;
+        if (magmin >= 0.0) {
+            // the median's |F|^2 lies in [bits(lo<<19), bits((hi+1)<<19)); sqrtf and mag2_threshold are monotone, so the capacity
+            // threshold T2 = mag2_threshold(magmin * sqrtf(.)) lies in [t2_lo, t2_hi]
+            const float m_lo = sqrtf(__uint_as_float(lo << 19)), m_hi = sqrtf(__uint_as_float(hi >= 4079u ? 0x7F7FFFFFu : ((hi + 1u) << 19)));
+            s->t2_lo = mag2_threshold(magmin * (double)m_lo);
+            s->t2_hi = mag2_threshold(magmin * (double)m_hi);
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
 }
@@ -1083,8 +1099,29 @@ __device__ __forceinline__ void bracket_load(BracketSeg& r, const float2* __rest
     r.partner = make_float2(0.f, 0.f);
     if (x0 == 0 && lane == 0) r.partner = pl[(size_t)((PH - y) & (PH - 1)) * M];
 }
+// columns x of row y (full-grid indices) with s_lo <= y*y + x*x <= s_hi: [a, b], empty when a > b
+__device__ __forceinline__ void annulus_row(unsigned long long yy, unsigned long long s_lo, unsigned long long s_hi, int& a, int& b) {
+    if (yy > s_hi) { a = 1; b = 0; return; }
+    unsigned long long hb = (unsigned long long)sqrt((double)(s_hi - yy));
+    while ((hb + 1) * (hb + 1) + yy <= s_hi) hb++;
+    while (hb * hb + yy > s_hi) hb--;
+    unsigned long long la = 0;
+    if (s_lo > yy) {
+        la = (unsigned long long)sqrt((double)(s_lo - yy));
+        while (la * la + yy < s_lo) la++;
+        while (la > 0 && (la - 1) * (la - 1) + yy >= s_lo) la--;
+    }
+    a = (int)(la > 0x3FFFFFFFull ? 0x3FFFFFFFull : la); b = (int)(hb > 0x3FFFFFFFull ? 0x3FFFFFFFull : hb);
+}
+// CAP: capacity (S:998-1008) counted in the same pass.  A stored bin (y, x), 0 < x < M, stands for the full-grid bins (y, x)
+// and its mirror ((PH-y)%PH, PW-x) of equal magnitude; each counts when it is off the axes and inside the annulus.  Per row
+// that is two column intervals (wave uniform), per element two range tests and a compare against the bracket of the
+// threshold (SelectState::t2_lo/t2_hi); the few values inside that bracket are parked for k_capacity_settle.
+template <bool CAP>
 __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
-                                  SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+                                  SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride,
+                                  unsigned long long s_lo, unsigned long long s_hi, int PWfull, unsigned* __restrict__ partial,
+                                  float* __restrict__ amb) {
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 1024 level-2 counters
     unsigned* wbuf = hist + 1024;                                 // 4 waves x 512 staged candidates
     unsigned* wcnt = wbuf + 4 * 512;                              // per wave: [0] staged count, [1] global base
@@ -1104,6 +1141,35 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
     unsigned below32 = 0;               // per lane < 2^32: a lane sees at most PH*PW/64 weights
     unsigned nstaged = 0;               // wave uniform
     const unsigned span = hi - lo;
+    // capacity: intervals of the current row (wave uniform), definite count, parked values
+    int ca1 = 1, cb1 = 0, ca2 = 1, cb2 = 0;
+    unsigned capcount = 0;
+    const float t2_lo = CAP ? s->t2_lo : 0.f, t2_hi = CAP ? s->t2_hi : 0.f;
+    float* amb_out = CAP ? amb + ((size_t)blockIdx.z * 3 + blockIdx.y) * TFFT_AMB_CAP : nullptr;
+    auto cap_row = [&](int y) {
+        ca1 = ca2 = 1; cb1 = cb2 = 0;
+        if (y == 0 || 2 * y == PH) return;                   // excluded rows (S:698-700); the mirror row is excluded with it
+        annulus_row((unsigned long long)y * (unsigned long long)y, s_lo, s_hi, ca1, cb1);
+        if (ca1 < 1) ca1 = 1;
+        if (cb1 > M - 1) cb1 = M - 1;
+        int ma, mb;                                          // mirror row PH-y, mirror columns xm in [ma, mb] -> stored x = PW - xm
+        const unsigned long long ym = (unsigned long long)(PH - y);
+        annulus_row(ym * ym, s_lo, s_hi, ma, mb);
+        ca2 = PWfull - mb; cb2 = PWfull - ma;
+        if (ma > mb) { ca2 = 1; cb2 = 0; }
+        if (ca2 < 1) ca2 = 1;
+        if (cb2 > M - 1) cb2 = M - 1;
+    };
+    auto cap_elem = [&](int x, float m2) {
+        const unsigned w = ((x >= ca1 && x <= cb1) ? 1u : 0u) + ((x >= ca2 && x <= cb2) ? 1u : 0u);
+        if (!(m2 < t2_hi)) capcount += w;
+        else if (w && !(m2 < t2_lo)) {                       // rare (a few bins per plane): settle once the median is known
+            for (unsigned k = 0; k < w; k++) {
+                const unsigned slot = atomicAdd(&s->n_amb, 1u);
+                if (slot < TFFT_AMB_CAP) amb_out[slot] = m2;
+            }
+        }
+    };
     auto classify = [&](bool valid, unsigned b, unsigned w) {
         const unsigned bk = b >> 19;
         below32 += (valid && bk < lo) ? w : 0u;
@@ -1130,6 +1196,8 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
         const bool nhave = ny < PH;
         BracketSeg nxt;
         if (nhave) bracket_load(nxt, pl, PH, M, ny, nx0, lane);
+        if (CAP && x0 == 0) cap_row(y);
+        const bool cap_live = CAP && (ca1 <= cb1 || ca2 <= cb2);      // wave uniform
         if (x0 == 0) {                  // packed column 0 (lane 0): F[y][0] and F[y][M], once each (unpack_col0)
             const float2 a = make_float2(cur.v[0].x, cur.v[0].y), b2 = cur.partner;
             const float2 f0 = make_float2(0.5f * (a.x + b2.x), 0.5f * (a.y - b2.y));
@@ -1140,8 +1208,10 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int x = x0 + 2 * (q * 64 + lane);
-            classify(x != 0 && x < M, __float_as_uint(mag2_of(make_float2(cur.v[q].x, cur.v[q].y))), 2u);
-            classify(x + 1 < M, __float_as_uint(mag2_of(make_float2(cur.v[q].z, cur.v[q].w))), 2u);
+            const float ma2 = mag2_of(make_float2(cur.v[q].x, cur.v[q].y)), mb2 = mag2_of(make_float2(cur.v[q].z, cur.v[q].w));
+            classify(x != 0 && x < M, __float_as_uint(ma2), 2u);
+            classify(x + 1 < M, __float_as_uint(mb2), 2u);
+            if (cap_live) { cap_elem(x, ma2); cap_elem(x + 1, mb2); }          // x = 0 and x >= M fall outside [1, M-1] by themselves
             if ((q & 1) && nstaged > 250) {     // at most 4 * 64 + 2 more before the next check: 508 <= 512
                 WaveSync::sync();
                 if (lane == 0) cnt[1] = atomicAdd(&s->n_cand, nstaged);
@@ -1166,6 +1236,38 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
     __syncthreads();
     for (int i = threadIdx.x; i < 1024; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+    if (CAP) {                          // one partial count per block (plain store, no global atomics)
+        __syncthreads();
+        if (threadIdx.x == 0) wcnt[0] = 0;
+        __syncthreads();
+        if (capcount) atomicAdd(&wcnt[0], capcount);
+        __syncthreads();
+        if (threadIdx.x == 0) partial[((size_t)blockIdx.z * 3 + blockIdx.y) * gridDim.x + blockIdx.x] = wcnt[0];
+    }
+}
+
+// usable[img] = sum_p floor(c_p / 2) from the bracket pass: c_p = the blocks' definite counts + the parked values that reach
+// T2 = mag2_threshold(magmin * median_p).  One block of three waves per image.  When a plane's median came from the fallback
+// select (its bracket was wrong) or it parked more than TFFT_AMB_CAP values, flag[img] = 1: k_capacity recounts that image.
+__global__ void k_capacity_settle(const SelectState* __restrict__ st, const float* __restrict__ med, double magmin, const unsigned* __restrict__ partial,
+                                  int nb, const float* __restrict__ amb, unsigned long long* __restrict__ usable, unsigned* __restrict__ flag) {
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3] + bad
+    unsigned* bad = reinterpret_cast<unsigned*>(c + 3);
+    const int img = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 3) c[threadIdx.x] = 0;
+    if (threadIdx.x == 0) bad[0] = 0;
+    __syncthreads();
+    const SelectState* s = st + (size_t)img * 3 + p;
+    const unsigned n_amb = s->n_amb;
+    if (lane == 0 && (!s->fast || n_amb > TFFT_AMB_CAP)) atomicOr(&bad[0], 1u);
+    const float t2 = mag2_threshold(magmin * (double)med[img * 3 + p]);
+    unsigned long long a = 0;
+    for (int i = lane; i < nb; i += 64) a += partial[((size_t)img * 3 + p) * nb + i];
+    const float* av = amb + ((size_t)img * 3 + p) * TFFT_AMB_CAP;
+    for (unsigned i = lane; i < n_amb && i < TFFT_AMB_CAP; i += 64) if (!(av[i] < t2)) a++;
+    if (a) atomicAdd(&c[p], a);
+    __syncthreads();
+    if (threadIdx.x == 0) { usable[img] = c[0] / 2 + c[1] / 2 + c[2] / 2; flag[img] = bad[0]; }
 }
 
 // LEVEL 2: verify the bracket and pick the 2048-wide sub-bucket; LEVEL 3: the exact value.
@@ -1196,7 +1298,7 @@ __global__ void k_select_fast(SelectState* __restrict__ st, float* __restrict__ 
         find_bucket(h, p1, p2, rank, NB, b, before);
         if (threadIdx.x == 0) {
             if (LEVEL == 2) { s->prefix = (unsigned)b; s->rank = rank - before; s->done = 2; }
-            else { med_out[blockIdx.x] = sqrtf(__uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b)); s->done = 1; }
+            else { med_out[blockIdx.x] = sqrtf(__uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b)); s->done = 1; s->fast = 1; }
         }
     } else if (threadIdx.x == 0) {
         s->n_cand = 0; s->prefix = 0; s->done = 0;      // s->rank is untouched: the fallback starts from it
@@ -1298,7 +1400,8 @@ __global__ void k_collect(const float2* __restrict__ spec, int PH, int M, size_t
 // WIDE: grids beyond 32768 need 64-bit y*y+x*x
 template <bool WIDE>
 __global__ void __launch_bounds__(256) k_capacity(const float2* __restrict__ spec, CapParams P, const float* __restrict__ med_dev,
-                           unsigned* __restrict__ partial) {
+                           unsigned* __restrict__ partial, const unsigned* __restrict__ only_flagged) {
+    if (only_flagged && !only_flagged[blockIdx.z]) return;      // batch path: only the images the bracket pass could not settle
     unsigned* blk = reinterpret_cast<unsigned*>(tfft_smem);
     if (threadIdx.x == 0) blk[0] = 0;
     __syncthreads();
@@ -1335,7 +1438,9 @@ __global__ void __launch_bounds__(256) k_capacity(const float2* __restrict__ spe
     if (threadIdx.x == 0) partial[((size_t)img * 3 + plane) * gridDim.x + blockIdx.x] = blk[0];
 }
 // usable[img] = sum_p floor(c_p/2): one block of three waves per image, wave p sums the partials of plane p
-__global__ void k_capacity_final(const unsigned* __restrict__ partial, int nb, unsigned long long* __restrict__ usable) {
+__global__ void k_capacity_final(const unsigned* __restrict__ partial, int nb, unsigned long long* __restrict__ usable,
+                                 const unsigned* __restrict__ only_flagged) {
+    if (only_flagged && !only_flagged[blockIdx.x]) return;
     unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3]
     const int img = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 3) c[threadIdx.x] = 0;
@@ -1691,19 +1796,20 @@ static unsigned stat_blocks(int rows, int n_images) {
 
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident,
-                          hipStream_t s) {
+                          hipStream_t s, const CapParams* cap, unsigned* partial, float* amb, unsigned long long* usable) {
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
     const unsigned nb = stat_blocks(PH, n_images);
     const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
     const dim3 g3(nb, 3, n_images), gs(3 * n_images);
+    unsigned nbc_used = 0;
     hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
     if (!force_fallback) {
         // fast path: sample histogram -> bracket -> one verified pass
         int step = PH / 128; if (step < 1) step = 1; if (step > 16) step = 16;      // sample every step-th row
         unsigned nbs = (unsigned)((PH + step - 1) / step); if (nbs > nb) nbs = nb; if (nbs < 1) nbs = 1;
         hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
-        hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st);
+        hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0);
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
         // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
         // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
@@ -1712,8 +1818,13 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         if (nbc > (unsigned)((PH + 3) / 4)) nbc = (unsigned)((PH + 3) / 4);
         if (nbc > TFFT_STAT_MAX_BLOCKS) nbc = TFFT_STAT_MAX_BLOCKS;
         if (nbc < 1) nbc = 1;
-        hipLaunchKernelGGL(k_collect_bracket, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
-                           img_stride, st, cand, cand_stride);
+        nbc_used = nbc;
+        if (cap)
+            hipLaunchKernelGGL(k_collect_bracket<true>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
+                               img_stride, st, cand, cand_stride, cap->s_lo, cap->s_hi, cap->PW, partial, amb);
+        else
+            hipLaunchKernelGGL(k_collect_bracket<false>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
+                               img_stride, st, cand, cand_stride, 0ull, 0ull, 0, nullptr, nullptr);
         hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
         hipLaunchKernelGGL(k_hist_cand<true>, dim3(16, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
@@ -1725,18 +1836,26 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
     hipLaunchKernelGGL(k_hist_cand<false>, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
     hipLaunchKernelGGL(k_select<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    if (cap) {
+        // capacity: settle the bracket pass's counts with the now known medians; images it could not settle (fallback median,
+        // overflowing park list, forced fallback: n_amb stays 0 but fast stays 0 too) are recounted by the plain kernel
+        unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;      // n_images words behind the partial counts
+        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)nbc_used, amb, usable, flag);
+        hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 
 // workgroups of k_collect_bracket that one CU holds at a time (queried once per context)
 int collect_bracket_resident_blocks() {
     int r = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_collect_bracket, 256, (1024 + 4 * 512 + 8) * sizeof(unsigned)) != hipSuccess) r = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, k_collect_bracket<true>, 256, (1024 + 4 * 512 + 8) * sizeof(unsigned)) != hipSuccess) r = 0;
     return r;
 }
 
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
-                           unsigned* partial, unsigned long long* usable, hipStream_t s) {
+                           unsigned* partial, unsigned long long* usable, hipStream_t s, const unsigned* only_flagged) {
     // about a dozen rows of the box per block (plain stores of the partial counts, no atomics): long
     // enough to amortise a block's start-up (threshold search, barrier), short enough that the grid still
     // has thousands of blocks with four loads per thread in flight; a single image gets more, shorter blocks
@@ -1749,9 +1868,9 @@ hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images,
     const unsigned nb = (unsigned)nbi;
     // the exact integer radius test fits 32 bits up to 32768 x 32768 and when the host bounds do
     const bool wide = P.PH > 32768 || P.PW > 32768 || P.s_hi > 0xFFFFFFFFull || P.s_lo > 0xFFFFFFFFull;
-    if (wide) hipLaunchKernelGGL(k_capacity<true>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
-    else hipLaunchKernelGGL(k_capacity<false>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial);
-    hipLaunchKernelGGL(k_capacity_final, dim3(n_images), dim3(192), 32, s, partial, (int)nb, usable);
+    if (wide) hipLaunchKernelGGL(k_capacity<true>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial, only_flagged);
+    else hipLaunchKernelGGL(k_capacity<false>, dim3(nb, 3, n_images), dim3(256), 16, s, spec, P, med_dev, partial, only_flagged);
+    hipLaunchKernelGGL(k_capacity_final, dim3(n_images), dim3(192), 32, s, partial, (int)nb, usable, only_flagged);
     return hipGetLastError();
 }
 

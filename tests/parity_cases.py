@@ -586,3 +586,38 @@ def check_stream_batch(lib, orc, bufs, w, h, secrets=(40, 40, 40, 100, 100), slo
     with pytest.raises(B.TfftError):
         ctx.embed_stream_batch_dev(1, bp, w, h, pb, n_bins, hop, pop, max_plen + 100, bp)
     ctx.close()
+
+
+def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0))):
+    """Capacity counted inside the medians' full pass (batch path, S:998-1008) == tfft_capacity with thr = magmin * median,
+    image by image, exactly: default annulus, an annulus that reaches into the mirror half (rmax > 0.5), thresholds at and
+    above the median (thousands of bins inside the threshold's bracket: the parked list overflows and the plain kernel
+    recounts), magmin = 0, and the forced median fallback."""
+    imgs = np.stack([cover_rgb(w, h, 70 + i) for i in range(nimg)])
+    ph, pw = 1 << (h - 1).bit_length(), 1 << (w - 1).bit_length()
+    bins = B.Walk(bytes(range(32)), ph, pw, 0.0, 1.5, 0.9, lib=lib).next(16)
+    bits = np.ones((nimg, 16), np.uint8)
+    ii, ip = bufs.put(imgs); ki, kp = bufs.put(bins.view(np.uint8).reshape(-1, 8)); bi, bp = bufs.put(bits)
+    oi, op = bufs.put(np.zeros_like(imgs))
+    one = B.Context(w, h, lib=lib)
+    want = {}
+    for (rmin, rmax, magmin) in cases:
+        for i in range(nimg):
+            one.forward_rgb8(imgs[i])
+            want[(rmin, rmax, magmin, i)] = one.capacity(magmin * one.medians(), rmin, rmax)
+    one.close()
+    for env in ({}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"}):
+        os.environ.update(env)
+        try:
+            ctx = B.Context(w, h, slots=2, lib=lib)
+        finally:
+            for k in env:
+                del os.environ[k]
+        for (rmin, rmax, magmin) in cases:
+            ui, up = bufs.put(np.full(nimg, -1, np.int64))
+            ctx.embed_batch_dev(nimg, ip, w, h, kp, bp, 16, op, rmin=rmin, rmax=rmax, magmin=magmin, usable_ptr=up)
+            ctx.sync()
+            got = bufs.get(ui)
+            for i in range(nimg):
+                assert int(got[i]) == want[(rmin, rmax, magmin, i)], (env, rmin, rmax, magmin, i, int(got[i]), want[(rmin, rmax, magmin, i)])
+        ctx.close()

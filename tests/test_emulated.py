@@ -319,3 +319,8 @@ def test_cover_hash_matches_the_reference(emu, golden_dir):
 def test_stream_batch_two_phase_extract(emu, orc):
     PC.check_stream_batch(emu, orc, PC.HostBufs, 256, 256, secrets=(8, 8, 20, 20, 8), slots=3, sort=True)
     PC.check_stream_batch(emu, orc, PC.HostBufs, 256, 128, secrets=(1,), slots=1, sort=False)
+
+
+def test_batch_capacity_inside_the_median_pass(emu):
+    PC.check_batch_capacity(emu, PC.HostBufs, 96, 64)
+    PC.check_batch_capacity(emu, PC.HostBufs, 40, 200, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.5)))

@@ -547,3 +547,9 @@ def test_stream_batch_two_phase_extract(lib, orc):
     PC.check_stream_batch(lib, orc, PC.TorchBufs, 512, 256, secrets=(64,) * 9 + (200,) * 2, slots=16, sort=True)
     PC.check_stream_batch(lib, orc, PC.TorchBufs, 2048, 2048, secrets=(4096,) * 8, slots=12, sort=True)
     PC.check_stream_batch(lib, orc, PC.TorchBufs, 256, 128, secrets=(1,), slots=1, sort=False)
+
+
+def test_batch_capacity_inside_the_median_pass(lib):
+    PC.check_batch_capacity(lib, PC.TorchBufs, 640, 360)
+    PC.check_batch_capacity(lib, PC.TorchBufs, 1920, 1080, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0)))
+    PC.check_batch_capacity(lib, PC.TorchBufs, 100, 2000, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.5)))

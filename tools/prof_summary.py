@@ -5,12 +5,12 @@ import csv, sys, collections, os, json
 d = sys.argv[1]
 def short(n):
     n = n.replace('tfft::', '').replace('void ', '')
-    return n.split('(')[0][:40]
+    return n.split('(')[0][:48]
 stats = {}
 for r in csv.DictReader(open(os.path.join(d, 'trace_kernel_stats.csv'))):
     stats[short(r['Name'])] = (int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage']))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
+for f in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
     p = os.path.join(d, f + '_counter_collection.csv')
     if not os.path.exists(p): continue
     for r in csv.DictReader(open(p)):
