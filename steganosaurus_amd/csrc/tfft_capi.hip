@@ -87,6 +87,13 @@ struct tfft_ctx {
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
     int median_force_fallback = 0;
+#ifndef TFFT_NO_GRAPHS
+    // launch-bound calls (a few images): the launch sequence of a batch call is captured once into a hipGraph, keyed by every
+    // argument, and replayed.  state 1 = seen once (the next call captures), exec != nullptr = replay
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int state = 0; };
+    std::map<std::vector<uint64_t>, GraphEntry> graphs;
+#endif
+    int graph_max_images = 4;             // TFFT_GRAPHS=0 disables; larger calls are bandwidth bound and gain nothing
     int stats_fused = 1;                  // TFFT_STATS_FUSED=0: capacity as its own pass after the medians (A/B)
     int fuse = 1;
 
@@ -165,6 +172,7 @@ enum Stage { ROWS_FWD = 0, COLS_FWD_A = 1, COLS_FWD_B = 2, EMBED = 3, COLS_INV_A
              N_STAGES = 11 };
 
 int get_dc_table(tfft_ctx* c, int valid, int N, int center, int kind, double scale, const float2** out);
+void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw device pointers: dropped whenever a buffer is reallocated
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
@@ -350,6 +358,7 @@ int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams*
 int ensure_stage(tfft_ctx* c, uint64_t n) {
     if (n <= c->stage_cap) return TFFT_OK;
     (void)hipStreamSynchronize(c->stream);
+    invalidate_graphs(c);
     if (c->stage_bins) { (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out); }
     c->stage_bins = c->stage_bits = c->stage_jit = c->stage_out = nullptr; c->stage_cap = 0;
     size_t cap = (size_t)n + (size_t)n / 4 + 1024;
@@ -369,6 +378,57 @@ int check_err_flag(tfft_ctx* c) {
         return TFFT_E_BIN_RANGE;
     }
     return TFFT_OK;
+}
+
+// ---- hipGraph replay of launch-bound batch calls ---------------------------------------------------------------
+void invalidate_graphs(tfft_ctx* c) {
+#ifndef TFFT_NO_GRAPHS
+    for (auto& kv : c->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    c->graphs.clear();
+#else
+    (void)c;
+#endif
+}
+inline uint64_t key_bits(double v) { uint64_t u; memcpy(&u, &v, sizeof u); return u; }
+inline uint64_t key_bits(const void* p) { return (uint64_t)(uintptr_t)p; }
+// enqueue(): the normal launch sequence on c->stream.  after(): the host-side slot state the sequence leaves behind (replays skip
+// the host code of enqueue()).  First call with a key: plain launches (every table / buffer the sequence needs is created here,
+// outside any capture).  Second call: captured + instantiated + launched.  Later calls: one hipGraphLaunch.
+template <class Enqueue, class After>
+int with_graph(tfft_ctx* c, int n_images, const std::vector<uint64_t>& key, Enqueue&& enqueue, After&& after) {
+#ifndef TFFT_NO_GRAPHS
+    if (c->graph_max_images > 0 && n_images > 0 && n_images <= c->graph_max_images && c->n_streams < 2) {
+        if (c->graphs.size() > 64) invalidate_graphs(c);
+        auto& e = c->graphs[key];
+        if (e.exec) {
+            HIPCHK(c, hipGraphLaunch(e.exec, c->stream));
+            return after();
+        }
+        if (e.state == 1) {
+            e.state = 2;            // whatever happens, do not try to capture this key again
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = enqueue();
+                hipGraph_t g = nullptr;
+                const hipError_t ee = hipStreamEndCapture(c->stream, &g);
+                hipGraphExec_t ex = nullptr;
+                if (rc == TFFT_OK && ee == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(g);
+                    c->graphs[key].exec = ex;
+                    HIPCHK(c, hipGraphLaunch(ex, c->stream));
+                    return after();
+                }
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                c->last_hip = 0;
+                return enqueue();       // capture refused or broken (nothing ran): plain launches; a genuine error shows up again here
+            }
+            (void)hipGetLastError();
+        } else if (e.state == 0) e.state = 1;
+    }
+#else
+    (void)n_images; (void)key; (void)after;
+#endif
+    return enqueue();
 }
 
 bool slot_ok(const tfft_ctx* c, int slot) { return c && slot >= 0 && slot < c->n_slots; }
@@ -419,6 +479,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_STATS_FUSED")) c->stats_fused = atoi(e);
+    if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
@@ -452,6 +513,7 @@ int tfft_destroy(tfft_ctx* c) {
     if (!c) return TFFT_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); }
@@ -474,6 +536,7 @@ int tfft_destroy(tfft_ctx* c) {
 
 int tfft_set_stream(tfft_ctx* c, void* hip_stream) {
     if (!c) return TFFT_E_INVALID;
+    invalidate_graphs(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
@@ -581,6 +644,7 @@ int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
 
 int tfft_set_bit_index(tfft_ctx* c, const uint32_t* bit_index, uint64_t n) {
     if (!c) return TFFT_E_INVALID;
+    invalidate_graphs(c);
     if (!bit_index || n == 0) {            // back to "bins[i] carries bit i"
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->bit_index);
@@ -728,6 +792,7 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
     if (n > b.cap || !b.ent) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        invalidate_graphs(c);
         (void)hipFree(b.ent); b.ent = nullptr; b.cap = 0;
         const uint64_t cap = n + n / 4 + 1024;
         if (dev_alloc(c, (void**)&b.ent, cap * sizeof(TileBin))) return TFFT_E_NOMEM;
@@ -736,6 +801,7 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
     if (nb + 1 > b.nb_cap || !b.cnt) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        invalidate_graphs(c);
         (void)hipFree(b.cnt); (void)hipFree(b.off); b.cnt = b.off = nullptr; b.nb_cap = 0;
         if (dev_alloc(c, (void**)&b.cnt, (size_t)(nb + 1) * sizeof(unsigned)) || dev_alloc(c, (void**)&b.off, (size_t)(nb + 1 + (nb + 1023) / 1024) * sizeof(unsigned)))
             return TFFT_E_NOMEM;
@@ -807,10 +873,9 @@ static int split_join(tfft_ctx* c) {
     return TFFT_OK;
 }
 
-int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
-                         const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
-                         void* usable_out_dev, void* rgb_out_dev) {
-    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || (n_bits && (!bins_dev || !bits_dev))) return TFFT_E_INVALID;
+static int embed_batch_dev_impl(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                                void* usable_out_dev, void* rgb_out_dev) {
     const size_t img_bytes = (size_t)w * h * 3;
     for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
@@ -832,9 +897,30 @@ int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, 
     return TFFT_OK;
 }
 
-int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
-                           uint64_t n_bits, double alpha, void* bits_out_dev) {
-    if (!c || n_images < 0 || !rgb_dev || (n_bits && (!bins_dev || !bits_out_dev))) return TFFT_E_INVALID;
+// host-side state a batch call leaves behind (what a graph replay has to redo): geometry set, no spectrum in any slot
+static int batch_after(tfft_ctx* c, int n_images, int w, int h, int center) {
+    const int g = n_images < c->n_slots ? n_images : c->n_slots;
+    int rc = batch_geometry(c, g, w, h, center);
+    if (rc) return rc;
+    for (int i = 0; i < g; i++) { c->slots[i].has_spec = false; c->slots[i].rgb_src = nullptr; }
+    return TFFT_OK;
+}
+
+int tfft_embed_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                         const void* bits_dev, uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                         void* usable_out_dev, void* rgb_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || (n_bits && (!bins_dev || !bits_dev))) return TFFT_E_INVALID;
+    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+    const std::vector<uint64_t> key = {1, (uint64_t)n_images, key_bits(rgb_dev), (uint64_t)w, (uint64_t)h, (uint64_t)center, key_bits(bins_dev), key_bits(bits_dev),
+                                       n_bits, key_bits(alpha), key_bits(rmin), key_bits(rmax), key_bits(magmin), key_bits(usable_out_dev),
+                                       key_bits(rgb_out_dev), key_bits(c->bit_index), key_bits((double)c->dc_bias)};
+    return with_graph(c, n_images, key,
+                      [&] { return embed_batch_dev_impl(c, n_images, rgb_dev, w, h, center, bins_dev, bits_dev, n_bits, alpha, rmin, rmax, magmin, usable_out_dev, rgb_out_dev); },
+                      [&] { return batch_after(c, n_images, w, h, center); });
+}
+
+static int extract_batch_dev_impl(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                  uint64_t n_bits, double alpha, void* bits_out_dev) {
     const size_t img_bytes = (size_t)w * h * 3;
     for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
@@ -854,12 +940,27 @@ int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w
     return TFFT_OK;
 }
 
+// the generic read path stages its parameter block with a host -> device copy per call: not captured
+static bool read_is_simple(double alpha) { return alpha > 0.0 && alpha < M_PI; }
+
+int tfft_extract_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                           uint64_t n_bits, double alpha, void* bits_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || (n_bits && (!bins_dev || !bits_out_dev))) return TFFT_E_INVALID;
+    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+    const std::vector<uint64_t> key = {2, (uint64_t)n_images, key_bits(rgb_dev), (uint64_t)w, (uint64_t)h, (uint64_t)center, key_bits(bins_dev), n_bits,
+                                       key_bits(alpha), key_bits(bits_out_dev), key_bits(c->bit_index), key_bits((double)c->dc_bias)};
+    return with_graph(c, read_is_simple(alpha) ? n_images : 0, key,
+                      [&] { return extract_batch_dev_impl(c, n_images, rgb_dev, w, h, center, bins_dev, n_bits, alpha, bits_out_dev); },
+                      [&] { return batch_after(c, n_images, w, h, center); });
+}
+
 // ---------------------------------------------------------------- packed-byte streams (SURVEY 8 f-3 wired into the pipelines)
 static int ensure_stream(tfft_ctx* c, uint64_t n_bins) {
     const size_t need = (size_t)c->n_slots * n_bins;
     if (need <= c->stream_cap && c->stream_plen) return TFFT_OK;
     (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    invalidate_graphs(c);
     (void)hipFree(c->stream_bits); c->stream_bits = nullptr; c->stream_cap = 0;
     if (dev_alloc(c, (void**)&c->stream_bits, need + 64)) return TFFT_E_NOMEM;
     c->stream_cap = need;
@@ -867,14 +968,11 @@ static int ensure_stream(tfft_ctx* c, uint64_t n_bins) {
     return TFFT_OK;
 }
 
-int tfft_embed_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
-                                uint64_t n_bins, const void* header_dev, const void* payload_dev, uint64_t payload_len, double alpha,
-                                double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev) {
-    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || !bins_dev || !header_dev || (payload_len && !payload_dev)) return TFFT_E_INVALID;
+static int embed_stream_batch_dev_impl(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                       uint64_t n_bins, const void* header_dev, const void* payload_dev, uint64_t payload_len, double alpha,
+                                       double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev) {
     const uint64_t n_bits = 38ull * 24 + payload_len * 56;           // S:986-995
-    if (n_bits > n_bins) return TFFT_E_INVALID;                      // the caller's walk is shorter than the stream
-    int rc = ensure_stream(c, n_bins);
-    if (rc) return rc;
+    int rc = TFFT_OK;
     const size_t img_bytes = (size_t)w * h * 3;
     for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
@@ -891,14 +989,28 @@ int tfft_embed_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, 
     return TFFT_OK;
 }
 
-int tfft_extract_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
-                                  uint64_t n_bins, double alpha, void* header_out_dev, void* payload_out_dev, uint64_t max_payload_len,
-                                  void* status_out_dev, void* raw_bits_out_dev) {
-    if (!c || n_images < 0 || !rgb_dev || !bins_dev || n_bins == 0 || !header_out_dev || !status_out_dev || (max_payload_len && !payload_out_dev))
-        return TFFT_E_INVALID;
+int tfft_embed_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                uint64_t n_bins, const void* header_dev, const void* payload_dev, uint64_t payload_len, double alpha,
+                                double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || !bins_dev || !header_dev || (payload_len && !payload_dev)) return TFFT_E_INVALID;
+    const uint64_t n_bits = 38ull * 24 + payload_len * 56;           // S:986-995
+    if (n_bits > n_bins) return TFFT_E_INVALID;                      // the caller's walk is shorter than the stream
+    if (!index_ok(c, n_bins)) return TFFT_E_STATE;
+    int rc = ensure_stream(c, n_bins);                                // (may reallocate: before any cached sequence is looked up)
+    if (rc) return rc;
+    const std::vector<uint64_t> key = {3, (uint64_t)n_images, key_bits(rgb_dev), (uint64_t)w, (uint64_t)h, (uint64_t)center, key_bits(bins_dev), n_bins,
+                                       key_bits(header_dev), key_bits(payload_dev), payload_len, key_bits(alpha), key_bits(rmin), key_bits(rmax),
+                                       key_bits(magmin), key_bits(usable_out_dev), key_bits(rgb_out_dev), key_bits(c->bit_index), key_bits((double)c->dc_bias)};
+    return with_graph(c, n_images, key,
+                      [&] { return embed_stream_batch_dev_impl(c, n_images, rgb_dev, w, h, center, bins_dev, n_bins, header_dev, payload_dev, payload_len, alpha,
+                                                               rmin, rmax, magmin, usable_out_dev, rgb_out_dev); },
+                      [&] { return batch_after(c, n_images, w, h, center); });
+}
+
+static int extract_stream_batch_dev_impl(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                         uint64_t n_bins, double alpha, void* header_out_dev, void* payload_out_dev, uint64_t max_payload_len,
+                                         void* status_out_dev, void* raw_bits_out_dev) {
     int rc = TFFT_OK;
-    if (!raw_bits_out_dev) { rc = ensure_stream(c, n_bins); if (rc) return rc; }
-    else if (!c->stream_plen && dev_alloc(c, (void**)&c->stream_plen, (size_t)c->n_slots * sizeof(unsigned))) return TFFT_E_NOMEM;
     const size_t img_bytes = (size_t)w * h * 3;
     for (int i0 = 0; i0 < n_images; i0 += c->n_slots) {
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
@@ -913,6 +1025,24 @@ int tfft_extract_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev
                                        (uint8_t*)payload_out_dev + (size_t)i0 * max_payload_len, (int*)status_out_dev + i0, c->stream_plen, c->stream));
     }
     return TFFT_OK;
+}
+
+int tfft_extract_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, int w, int h, int center, const void* bins_dev,
+                                  uint64_t n_bins, double alpha, void* header_out_dev, void* payload_out_dev, uint64_t max_payload_len,
+                                  void* status_out_dev, void* raw_bits_out_dev) {
+    if (!c || n_images < 0 || !rgb_dev || !bins_dev || n_bins == 0 || !header_out_dev || !status_out_dev || (max_payload_len && !payload_out_dev))
+        return TFFT_E_INVALID;
+    if (!index_ok(c, n_bins)) return TFFT_E_STATE;
+    int rc = TFFT_OK;
+    if (!raw_bits_out_dev) { rc = ensure_stream(c, n_bins); if (rc) return rc; }
+    else if (!c->stream_plen && dev_alloc(c, (void**)&c->stream_plen, (size_t)c->n_slots * sizeof(unsigned))) return TFFT_E_NOMEM;
+    const std::vector<uint64_t> key = {4, (uint64_t)n_images, key_bits(rgb_dev), (uint64_t)w, (uint64_t)h, (uint64_t)center, key_bits(bins_dev), n_bins,
+                                       key_bits(alpha), key_bits(header_out_dev), key_bits(payload_out_dev), max_payload_len, key_bits(status_out_dev),
+                                       key_bits(raw_bits_out_dev), key_bits(c->bit_index), key_bits((double)c->dc_bias)};
+    return with_graph(c, read_is_simple(alpha) ? n_images : 0, key,
+                      [&] { return extract_stream_batch_dev_impl(c, n_images, rgb_dev, w, h, center, bins_dev, n_bins, alpha, header_out_dev, payload_out_dev,
+                                                                 max_payload_len, status_out_dev, raw_bits_out_dev); },
+                      [&] { return batch_after(c, n_images, w, h, center); });
 }
 
 // ---------------------------------------------------------------- host-buffer batches

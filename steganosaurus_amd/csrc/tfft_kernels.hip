@@ -553,6 +553,16 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
                 dstw[w] = get(o) | (get(o + 1) << 8) | (get(o + 2) << 16) | (get(o + 3) << 24);
             }
             for (int o = head + 4 * nwords + tid; o < nbytes; o += nthr) dst[o] = (uint8_t)get(o);
+        } else if ((P.W & 1) == 0) {
+            // one plane per workgroup: the packed slot m holds pixels 2m and 2m+1 of this plane (as in k_colrow_inv); the generic
+            // byte loop below cost ~25 instructions per pixel (index division, single-float LDS reads) -- 30 % of this kernel's VALU work
+            const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+            uint8_t* d1 = dst + plane0;
+            for (int m = tid; m < (P.W >> 1); m += nthr) {
+                const float2 v = lds[lay.idx(m, 0)];
+                d1[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
+                d1[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
+            }
         } else {
             for (int n = tid; n < P.W; n += nthr) dst[3 * n + plane0] = (uint8_t)get(3 * n + plane0);
         }
@@ -1826,7 +1836,11 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
             hipLaunchKernelGGL(k_collect_bracket<false>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                                img_stride, st, cand, cand_stride, 0ull, 0ull, 0, nullptr, nullptr);
         hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
-        hipLaunchKernelGGL(k_hist_cand<true>, dim3(16, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
+        // candidates: ~13 % of a plane; 16 blocks per plane are plenty for a batch but left one 8192^2 image with 48 blocks in all (110 us)
+        unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
+        if (nbh < 16) nbh = 16;
+        if (nbh > 256) nbh = 256;
+        hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
     }
     // fallback: plain three-level select; every block returns immediately when the fast path verified

@@ -553,3 +553,54 @@ def test_batch_capacity_inside_the_median_pass(lib):
     PC.check_batch_capacity(lib, PC.TorchBufs, 640, 360)
     PC.check_batch_capacity(lib, PC.TorchBufs, 1920, 1080, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0)))
     PC.check_batch_capacity(lib, PC.TorchBufs, 100, 2000, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.5)))
+
+
+def test_graph_replay_matches_plain_launches(lib, orc):
+    """Launch-bound batch calls (<= 4 images) are captured into a hipGraph on their second use and replayed from the third:
+    every repetition returns what the plain launch sequence (TFFT_GRAPHS=0) returns, also after the inputs changed in place,
+    after a bit index was installed (cached sequences are dropped) and for a second geometry on the same context."""
+    import torch
+    dev = torch.device("cuda:0")
+    res = {}
+    for mode in ("4", "0"):
+        os.environ["TFFT_GRAPHS"] = mode
+        try:
+            ctx = B.Context(1920, 1080, slots=4, lib=lib)
+        finally:
+            del os.environ["TFFT_GRAPHS"]
+        out = []
+        for (w, h, nimg, secret) in ((1920, 1080, 1, 4096), (640, 360, 3, 64)):
+            ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+            plen = secret + 16
+            n_bins = 912 + 56 * plen + 300
+            bins = B.Walk(orc.subkeys(PC.PK)[0], ph, pw, lib=lib).next(n_bins)
+            d_bins = torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()).to(dev)
+            hdr = np.stack([PC.make_header(secret, i) for i in range(nimg)])
+            d_hdr = torch.from_numpy(hdr).to(dev)
+            d_img = torch.zeros((nimg, h, w, 3), dtype=torch.uint8, device=dev)
+            d_pay = torch.zeros((nimg, plen), dtype=torch.uint8, device=dev)
+            d_out = torch.zeros_like(d_img); d_us = torch.zeros(nimg, dtype=torch.int64, device=dev)
+            d_h2 = torch.zeros((nimg, 38), dtype=torch.uint8, device=dev); d_p2 = torch.zeros((nimg, plen), dtype=torch.uint8, device=dev)
+            d_st = torch.zeros(nimg, dtype=torch.int32, device=dev); d_raw = torch.zeros((nimg, n_bins), dtype=torch.uint8, device=dev)
+            for rep in range(5):
+                if rep == 3:
+                    sb, idx = B.bins_sort(bins, lib=lib)
+                    d_bins.copy_(torch.from_numpy(sb.view(np.uint8).reshape(-1, 8).copy()).to(dev))
+                    ctx.set_bit_index(idx)
+                # new content in the SAME buffers every repetition
+                d_img.copy_(torch.from_numpy(np.stack([cover_rgb(w, h, 10 * rep + i) for i in range(nimg)])).to(dev))
+                d_pay.copy_(torch.from_numpy(np.random.default_rng(rep).integers(0, 256, (nimg, plen)).astype(np.uint8)).to(dev))
+                torch.cuda.synchronize()
+                ctx.embed_stream_batch_dev(nimg, d_img.data_ptr(), w, h, d_bins.data_ptr(), n_bins, d_hdr.data_ptr(), d_pay.data_ptr(), plen,
+                                           d_out.data_ptr(), usable_ptr=d_us.data_ptr())
+                ctx.extract_stream_batch_dev(nimg, d_out.data_ptr(), w, h, d_bins.data_ptr(), n_bins, d_h2.data_ptr(), d_p2.data_ptr(), plen,
+                                             d_st.data_ptr(), raw_bits_out_ptr=d_raw.data_ptr())
+                ctx.sync()
+                out.append([t.cpu().numpy().copy() for t in (d_out, d_us, d_h2, d_st, d_raw)])
+            ctx.set_bit_index(None)
+        ctx.close()
+        res[mode] = out
+    assert len(res["4"]) == len(res["0"]) == 10
+    for a, b in zip(res["4"], res["0"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
