@@ -96,6 +96,7 @@ struct tfft_ctx {
     int graph_max_images = 4;             // TFFT_GRAPHS=0 disables; larger calls are bandwidth bound and gain nothing
     int stats_fused = 1;                  // TFFT_STATS_FUSED=0: capacity as its own pass after the medians (A/B)
     int fuse = 1;
+    int fuse_wide = 1;
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
     float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
@@ -137,8 +138,10 @@ ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi = 0) {
     const int l = ilog2i(PH);
     ColPlan p;
     p.fused_fwd = false;
-    if (c->fuse && PWi == 2048 && l >= 7 && l - 3 <= 10 && c->cols_force_log_n1 < 0) {
-        // rows + first column step in one kernel (k_rowcol_fwd): PH = 8 * N2
+    if (c->fuse && c->cols_force_log_n1 < 0 && l >= 7 &&
+        ((PWi == 2048 && l - 3 <= 10) || (PWi == 4096 && c->fuse_wide && l - 3 <= 9))) {
+        // rows + first column step in one kernel (k_rowcol_fwd): PH = 8 * N2.  2048 wide: one wave per row; 4096 wide: two waves
+        // per row, 1024-thread workgroups (TFFT_FUSE_WIDE=0: the three-pass plan)
         p.direct = false; p.log_n1 = 3; p.log_n2 = l - 3; p.fused_fwd = true;
         return p;
     }
@@ -474,6 +477,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->n_cus = prop.multiProcessorCount;
     c->collect_resident = collect_bracket_resident_blocks();
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
+    if (const char* e = getenv("TFFT_FUSE_WIDE")) c->fuse_wide = atoi(e);
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);

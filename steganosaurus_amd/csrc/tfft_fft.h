@@ -190,6 +190,8 @@ __device__ __forceinline__ void fft_block(float2 (&u)[E], float2* lds, const Lay
 
 // Same passes with the twiddles read from the table at the point of use (no register prefetch): for
 // kernels whose occupancy is limited by VGPRs rather than by table latency.
+//   active (uniform over the threads that share a sequence): false = this thread's sequence does not exist (a padded
+//   row); it computes nothing and touches no LDS but still takes part in the workgroup barriers of BlockSync.
 template <int N, int E, int SIGN, int P, class Lay, class Sync>
 struct FftPassesLazy {
     static constexpr int R = imin(E, N / P);
@@ -197,46 +199,52 @@ struct FftPassesLazy {
     static constexpr int T = N / E;
     static constexpr int Q = E / R;
     static __device__ __forceinline__ void run(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
-                                               const float2* __restrict__ tw, int tws) {
+                                               const float2* __restrict__ tw, int tws, bool active) {
         float2 o[E];
+        if (active) {
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
-            float2 v[R];
+            for (int q = 0; q < Q; q++) {
+                float2 v[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) v[r] = u[q + r * Q];
-            const int i = t + q * T;
-            const int k = i & (P - 1);
-            if constexpr (P > 1) {
-                const int base = k * (N / (P * R)) * tws;
+                for (int r = 0; r < R; r++) v[r] = u[q + r * Q];
+                const int i = t + q * T;
+                const int k = i & (P - 1);
+                if constexpr (P > 1) {
+                    const int base = k * (N / (P * R)) * tws;
 #pragma unroll
-                for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
-            }
-            DftReg<R, SIGN, 0, R>::run(v);
-            if constexpr (LAST) {
+                    for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
+                }
+                DftReg<R, SIGN, 0, R>::run(v);
+                if constexpr (LAST) {
 #pragma unroll
-                for (int s = 0; s < R; s++) o[q + s * Q] = v[bitrev(s, ilog2(R))];
-            } else {
-                const int j = (i - k) * R + k;
+                    for (int s = 0; s < R; s++) o[q + s * Q] = v[bitrev(s, ilog2(R))];
+                } else {
+                    const int j = (i - k) * R + k;
 #pragma unroll
-                for (int s = 0; s < R; s++) lds[lay.idx(j + s * P, b)] = v[bitrev(s, ilog2(R))];
+                    for (int s = 0; s < R; s++) lds[lay.idx(j + s * P, b)] = v[bitrev(s, ilog2(R))];
+                }
             }
         }
         if constexpr (LAST) {
+            if (active) {
 #pragma unroll
-            for (int m = 0; m < E; m++) u[m] = o[m];
+                for (int m = 0; m < E; m++) u[m] = o[m];
+            }
         } else {
             Sync::sync();
+            if (active) {
 #pragma unroll
-            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, b)];
+                for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, b)];
+            }
             Sync::sync();
-            FftPassesLazy<N, E, SIGN, P * R, Lay, Sync>::run(u, lds, lay, t, b, tw, tws);
+            FftPassesLazy<N, E, SIGN, P * R, Lay, Sync>::run(u, lds, lay, t, b, tw, tws, active);
         }
     }
 };
 template <int N, int E, int SIGN, class Sync = BlockSync, class Lay>
 __device__ __forceinline__ void fft_block_lazy(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
-                                               const float2* __restrict__ tw, int tws) {
-    if constexpr (N > 1) FftPassesLazy<N, E, SIGN, 1, Lay, Sync>::run(u, lds, lay, t, b, tw, tws);
+                                               const float2* __restrict__ tw, int tws, bool active = true) {
+    if constexpr (N > 1) FftPassesLazy<N, E, SIGN, 1, Lay, Sync>::run(u, lds, lay, t, b, tw, tws, active);
 }
 
 // elements per thread for a length-N transform

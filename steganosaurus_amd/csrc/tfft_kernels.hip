@@ -227,10 +227,14 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
 // and re-reading the H x M intermediate.
 //   grid (3*N2, n_images) in xcd_plane_order   block (64, N1)   M = 1024, E = 16
 // ---------------------------------------------------------------------------
-template <int LOGN1>
-__global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out,
+// LOGM = 10: images up to 2048 wide, one wave per row (wave-level exchanges, no barrier inside the row transform).
+// LOGM = 11: up to 4096 wide, two waves per row, 1024-thread workgroups holding 8 x 16 KB rows (155 KB of LDS, one workgroup
+//            per CU); the row transform's exchanges are workgroup barriers, which the waves of padded rows just sit out.
+template <int LOGN1, int LOGM>
+__global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out,
                              const float2* __restrict__ tw, const float2* __restrict__ tw_h, RowParams P) {
-    constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
+    constexpr int M = 1 << LOGM, E = 16, T = M / E, N1 = 1 << LOGN1;
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
     const int t = threadIdx.x, n1 = threadIdx.y;
     const int N2 = P.PH >> LOGN1;
     int n2, plane;
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
     float2* lds = reinterpret_cast<float2*>(tfft_smem);
     float* ldsf = reinterpret_cast<float*>(tfft_smem);
     LayRows lay{LayRows::padded(M)};
-    const bool live = y < P.H;          // wave uniform: a row is exactly one wave
+    const bool live = y < P.H;          // wave uniform: a row is one or two whole waves
 
     // pass twiddles exp(+2 pi i j/M), j < M, staged once per workgroup behind the row slabs: the radix
     // passes then read them with LDS latency instead of L2 latency (8 KB; two workgroups still fit a CU)
@@ -298,19 +302,18 @@ __global__ void __launch_bounds__(64 << LOGN1) k_rowcol_fwd(const uint8_t* __res
         }
     }
     __syncthreads();                    // the twiddle table and every live row are staged
-    if (live) {
+    {
         float2 u[E];
+        if (live) {
 #pragma unroll
-        for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
-        WaveSync::sync();
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+        }
+        Sync::sync();
         // pass twiddles are read at the point of use from the LDS copy: prefetching them into registers
         // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
-        fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
+        fft_block_lazy<M, E, +1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
 #pragma unroll
-        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];      // Z = FFT of the packed (even, odd) row
-    } else {
-#pragma unroll
-        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = make_float2(0.f, 0.f);
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);      // Z = FFT of the packed (even, odd) row
     }
     __syncthreads();
 
@@ -369,12 +372,13 @@ __device__ __forceinline__ unsigned quantise_u8(float v) {
 // Replaces the second k_fft_cols inverse step followed by k_rows_inv.
 //   grid (3*N2, n_images) in xcd_plane_order   block (64, N1)   M = 1024, E = 16
 // ---------------------------------------------------------------------------
-template <int LOGN1>
+template <int LOGN1, int LOGM>
 // (140 VGPRs leave one workgroup of 8 waves per CU; forcing 128 with amdgpu_waves_per_eu(4) spills 19 dwords and
 // measured 0.71 ms against 0.58 ms)
-__global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
+__global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
                              const float2* __restrict__ tw, RowParams P) {
-    constexpr int M = 1024, E = 16, T = 64, N1 = 1 << LOGN1;
+    constexpr int M = 1 << LOGM, E = 16, T = M / E, N1 = 1 << LOGN1;
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
     const int t = threadIdx.x, n1 = threadIdx.y;
     const int N2 = P.PH >> LOGN1;
     int n2, plane;
@@ -426,17 +430,23 @@ __global__ void __launch_bounds__(64 << LOGN1) k_colrow_inv(const float2* __rest
 #pragma unroll
     for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
     __syncthreads();
-    if (y >= P.H) return;               // wave uniform (one wave per row); no barrier follows
+    const bool live = y < P.H;          // wave uniform (a row is one or two whole waves)
+    if (T == 64 && !live) return;       // one wave per row: no workgroup barrier follows
 
-    WaveSync::sync();
+    Sync::sync();
     float2 u[E];
+    if (live) {
 #pragma unroll
-    for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
-    WaveSync::sync();
-    fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
+        for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+    }
+    Sync::sync();
+    fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
+    if (live) {
 #pragma unroll
-    for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
-    WaveSync::sync();
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
+    }
+    Sync::sync();
+    if (!live) return;
 
     // ---- quantise and store this plane's bytes of row y
     uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
@@ -621,13 +631,19 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
     float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
+    // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH), k < L: staged once per workgroup behind the DC rows
+    // and read back at the stores (as registers they were 32 VGPRs: the L = 256 / 512 variants spilled 26 .. 79 dwords)
+    float2* lds_wo = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * (C + (DC ? 1 : 0)) + (size_t)gl * L;
     if (DC) {
         for (int k = t * C + c; k < L; k += T * C) {       // forward: rows of the outputs; inverse: rows of the inputs
             const int row = (SIGN > 0) ? P.out_a * k + P.out_b * g : P.in_a * k + P.in_b * g;
             lds_ah[k] = (g < P.G && row < P.PH) ? P.dc_ah[row] : make_float2(0.f, 0.f);
         }
-        __syncthreads();
     }
+    if (TW) {
+        for (int k = t * C + c; k < L; k += T * C) lds_wo[k] = twload<SIGN>(tw, (k * g) & (P.PH - 1));
+    }
+    if (DC || TW) __syncthreads();
     // COLS_READ: the buckets of this workgroup's tiles are consecutive (tile is the last digit of the bucket id), so
     // nine offsets tell which tiles carry bins at all; a tile without bins (beyond the annulus: a tenth of them with
     // rmax = 0.45) is neither loaded nor transformed.  Workgroup-uniform, so the barriers stay aligned.
@@ -653,11 +669,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     float2 W[tw_regs<L, E>()];
     fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
-    float2 wo[TW ? E : 1];      // output twiddles of the two-step decomposition, exp(SIGN*2*pi*i*k*g/PH)
-    if (TW) {
-#pragma unroll
-        for (int m = 0; m < E; m++) wo[TW ? m : 0] = twload<SIGN>(tw, ((t + m * T) * g) & (P.PH - 1));
-    }
     for (int tile = tile0; tile < tile1; tile++) {
         if (tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
         if (!has_bins(tile)) {
@@ -708,7 +719,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                 const int row = P.out_a * k + P.out_b * g;
                 if (row < out_rows) {
                     float2 v = u[m];
-                    if (TW) v = cmul(v, wo[TW ? m : 0]);
+                    if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
                     dst[(size_t)row * P.M] = v;
                 }
@@ -1685,24 +1696,37 @@ hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw,
 #undef F
     return hipSuccess;
 }
-hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
-                             int n_images, hipStream_t s) {
-    constexpr int LOGN1 = 3;
-    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024 + (1 << LOGN1)) * sizeof(float2);    // row slabs + twiddle tables
-    auto k = k_rowcol_fwd<LOGN1>;
+template <int LOGM>
+static hipError_t launch_rowcol_fwd_t(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
+                                      int n_images, hipStream_t s) {
+    constexpr int LOGN1 = 3, M = 1 << LOGM;
+    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(M) + M + (1 << LOGN1)) * sizeof(float2);    // row slabs + twiddle tables
+    auto k = k_rowcol_fwd<LOGN1, LOGM>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(64, 1 << LOGN1), lds, s, rgb, out, tw_pw, tw_ph, P);
+    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(M / 16, 1 << LOGN1), lds, s, rgb, out, tw_pw, tw_ph, P);
+    return hipGetLastError();
+}
+hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
+                             int n_images, hipStream_t s) {
+    if (P.PW == 2048) return launch_rowcol_fwd_t<10>(rgb, out, tw_pw, tw_ph, P, n_images, s);
+    if (P.PW == 4096) return launch_rowcol_fwd_t<11>(rgb, out, tw_pw, tw_ph, P, n_images, s);
+    return hipErrorInvalidValue;
+}
+template <int LOGM>
+static hipError_t launch_colrow_inv_t(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
+    constexpr int LOGN1 = 3, M = 1 << LOGM;
+    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(M) + M) * sizeof(float2);    // row slabs + twiddle table
+    auto k = k_colrow_inv<LOGN1, LOGM>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(M / 16, 1 << LOGN1), lds, s, in, rgb, tw_pw, P);
     return hipGetLastError();
 }
 hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
-    constexpr int LOGN1 = 3;
-    const size_t lds = ((size_t)(1 << LOGN1) * LayRows::padded(1024) + 1024) * sizeof(float2);    // row slabs + twiddle table
-    auto k = k_colrow_inv<LOGN1>;
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((P.PH >> LOGN1) * 3, n_images), dim3(64, 1 << LOGN1), lds, s, in, rgb, tw_pw, P);
-    return hipGetLastError();
+    if (P.PW == 2048) return launch_colrow_inv_t<10>(in, rgb, tw_pw, P, n_images, s);
+    if (P.PW == 4096) return launch_colrow_inv_t<11>(in, rgb, tw_pw, P, n_images, s);
+    return hipErrorInvalidValue;
 }
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s) {
@@ -1720,7 +1744,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (P.dc_ah ? (size_t)gpb * L * sizeof(float2) : 0);
+    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;

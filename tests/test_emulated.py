@@ -55,6 +55,13 @@ def test_fused_rows_plus_column_step(emu, orc):
     PC.check_identity_roundtrip(emu, [(1500, 130)])
 
 
+def test_fused_rows_plus_column_step_4096_wide(emu, orc):
+    # PW = 4096 and 128 <= PH <= 4096: the same fused kernels with two waves per row (workgroup barriers inside the row transform,
+    # which the waves of padded rows sit out): live rows only in the first rows of a workgroup, odd width, centring
+    PC.check_forward_against_oracle(emu, orc, [(2500, 130), (4095, 200)], centers=(0, 1))
+    PC.check_identity_roundtrip(emu, [(3000, 140), (4096, 128)])
+
+
 def test_identity_roundtrip(emu):
     PC.check_identity_roundtrip(emu, [(64, 64), (48, 40), (33, 17), (2, 2), (1, 1), (5, 1), (1, 7), (12, 1024)])
 
