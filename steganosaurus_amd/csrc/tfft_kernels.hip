@@ -38,6 +38,9 @@
 #ifndef TFFT_ROWS_LAZY_LOG
 #define TFFT_ROWS_LAZY_LOG 11
 #endif
+#ifndef TFFT_COLS_LDS_TW_LOG
+#define TFFT_COLS_LDS_TW_LOG 9
+#endif
 
 namespace tfft {
 
@@ -667,8 +670,18 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
     auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
-    float2 W[tw_regs<L, E>()];
-    fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
+    // inter-pass twiddles: registers (fetched once per workgroup) up to L = 256; for L = 512 they would be 46 more VGPRs in a kernel
+    // capped at 256 (8 waves): there the L-entry table exp(+2 pi i j/L) is staged in LDS and read at the point of use
+    constexpr bool TWL = (LOGL >= TFFT_COLS_LDS_TW_LOG);
+    float2 W[TWL ? 1 : tw_regs<L, E>()];
+    float2* lds_tw = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * (C + (DC ? 1 : 0) + (TW ? 1 : 0));
+    if (TWL) {
+        const int tws = P.PH >> LOGL;
+        for (int k = (gl * T + t) * C + c; k < L; k += blockDim.z * T * C) lds_tw[k] = tw[k * tws];
+        __syncthreads();
+    } else {
+        fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
+    }
     for (int tile = tile0; tile < tile1; tile++) {
         if (tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
         if (!has_bins(tile)) {
@@ -681,7 +694,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = csub(u[m], cmul(lds_ah[t + m * T], awc));
         }
-        fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
+        if (TWL) fft_block_lazy<L, E, SIGN>(u, lds, lay, t, c, lds_tw, 1);
+        else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
             __syncthreads();            // the last gather of fft_block has been consumed by every thread
@@ -1744,7 +1758,8 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0);
+    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
+                       (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;

@@ -55,6 +55,18 @@ def test_fused_rows_plus_column_step(emu, orc):
     PC.check_identity_roundtrip(emu, [(1500, 130)])
 
 
+def test_columns_of_512_with_lds_twiddles(emu, orc):
+    """PH = 1024 forced into 2 x 512: the L = 512 column kernels keep their inter-pass twiddles in LDS (all other lengths: registers);
+    forward, inverse (output twiddles + DC prologue) and the tile-resident read."""
+    os.environ["TFFT_COLS_LOG_N1"] = "1"
+    try:
+        PC.check_forward_against_oracle(emu, orc, [(40, 1000)], centers=(0, 1))
+        PC.check_identity_roundtrip(emu, [(24, 900)])
+        PC.check_embed_extract(emu, orc, 64, 1024, 300, dict(rmin=0.0, rmax=1.5, density=0.9))
+    finally:
+        del os.environ["TFFT_COLS_LOG_N1"]
+
+
 def test_fused_rows_plus_column_step_4096_wide(emu, orc):
     # PW = 4096 and 128 <= PH <= 4096: the same fused kernels with two waves per row (workgroup barriers inside the row transform,
     # which the waves of padded rows sit out): live rows only in the first rows of a workgroup, odd width, centring
