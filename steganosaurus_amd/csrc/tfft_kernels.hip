@@ -38,8 +38,11 @@
 #ifndef TFFT_ROWS_LAZY_LOG
 #define TFFT_ROWS_LAZY_LOG 11
 #endif
+// column kernels of length >= 2^this read their inter-pass twiddles from an LDS copy of the table instead of holding them in
+// registers.  Needed at 512 (no spills); measured at 256 as well (round 2 A/B, one box): final forward step 0.614 vs 0.640 ms
+// per 32x1080p launch, nothing lost elsewhere; shorter lengths: no difference
 #ifndef TFFT_COLS_LDS_TW_LOG
-#define TFFT_COLS_LDS_TW_LOG 9
+#define TFFT_COLS_LDS_TW_LOG 8
 #endif
 
 namespace tfft {
@@ -670,8 +673,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
     auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
-    // inter-pass twiddles: registers (fetched once per workgroup) up to L = 256; for L = 512 they would be 46 more VGPRs in a kernel
-    // capped at 256 (8 waves): there the L-entry table exp(+2 pi i j/L) is staged in LDS and read at the point of use
+    // inter-pass twiddles: registers (fetched once per workgroup) for short columns; from TFFT_COLS_LDS_TW_LOG on the L-entry table
+    // exp(+2 pi i j/L) is staged in LDS and read at the point of use (at L = 512 they would be 46 more VGPRs in a kernel capped at 256)
     constexpr bool TWL = (LOGL >= TFFT_COLS_LDS_TW_LOG);
     float2 W[TWL ? 1 : tw_regs<L, E>()];
     float2* lds_tw = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * (C + (DC ? 1 : 0) + (TW ? 1 : 0));
