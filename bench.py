@@ -170,7 +170,7 @@ class Workload:
         self.d_usable = torch.zeros(n_img, dtype=torch.int64, device=dev)
         self.slots = max(1, min(slots if slots > 0 else 32, n_img))
         self.ctx = S.Context(W, H, slots=self.slots, device=local)
-        self.plan = self.ctx.plan_info(W, H)          # which kernels this geometry takes (fused rows+columns, two-step columns)
+        self.plan = self.ctx.plan_info(W, H, min(self.slots, n_img))      # which kernels a launch over the chunk takes
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if self.sort_bins:
             self.ctx.set_bit_index(d_index.cpu().numpy().astype(np.uint32))

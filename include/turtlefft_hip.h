@@ -77,10 +77,11 @@ int tfft_set_stream(tfft_ctx* ctx, void* hip_stream);
 int tfft_sync(tfft_ctx* ctx);
 int tfft_last_hip_error(const tfft_ctx* ctx);
 size_t tfft_device_bytes(const tfft_ctx* ctx);
-/* Which kernels a w x h image takes on this context (measurement / documentation aid): info[0] = 1 when the column
- * transform is one pass, else it is two steps of lengths 2^info[1] and 2^info[2]; info[3] = 1 when the row pass is
- * fused with the adjacent column step (a 2-D transform is then two global passes). */
-int tfft_plan_info(const tfft_ctx* ctx, int w, int h, int info[4]);
+/* Which kernels a launch over n_images images of w x h takes on this context (measurement / documentation aid):
+ * info[0] = 1 when the column transform is one pass, else it is two steps of lengths 2^info[1] and 2^info[2];
+ * info[3] = 1 when the row pass is fused with the adjacent column step (a 2-D transform is then two global passes:
+ * always for images that pad to 2048 columns, for 4096 columns in launches of two or more images). */
+int tfft_plan_info(const tfft_ctx* ctx, int w, int h, int n_images, int info[4]);
 
 /* ------------------------------------------------------------- forward side
  * to_planes_u8 + apply_center + pad_to_fft + fft2d(forward) x3  (S:912-921,

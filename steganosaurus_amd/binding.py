@@ -55,7 +55,7 @@ SYMBOLS = {
     "tfft_extract_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp]),
     "tfft_host_alloc": (_vp, [C.c_size_t]),
     "tfft_host_free": (None, [_vp]),
-    "tfft_plan_info": (_i, [_vp, _i, _i, _pi]),
+    "tfft_plan_info": (_i, [_vp, _i, _i, _i, _pi]),
     "tfft_embed_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
     "tfft_extract_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp, _vp, _u64, _vp, _vp]),
     "tfft_walk_create": (_i, [C.c_char_p, _i, _i, _d, _d, _d, C.POINTER(_vp)]),
@@ -211,9 +211,9 @@ class Context:
         idx = np.ascontiguousarray(bit_index, np.uint32)
         _check(self.lib.tfft_set_bit_index(self.h, _ptr(idx), len(idx)), "tfft_set_bit_index")
 
-    def plan_info(self, w, h):
+    def plan_info(self, w, h, n_images=1):
         info = (C.c_int * 4)()
-        _check(self.lib.tfft_plan_info(self.h, w, h, info), "tfft_plan_info")
+        _check(self.lib.tfft_plan_info(self.h, w, h, n_images, info), "tfft_plan_info")
         return {"direct": bool(info[0]), "log_n1": info[1], "log_n2": info[2], "fused": bool(info[3]), "two_step": not info[0]}
 
     def device_bytes(self):

@@ -134,14 +134,16 @@ int get_twiddles(tfft_ctx* c, int n, const float2** out) {
     return TFFT_OK;
 }
 
-ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi = 0) {
+// n = images in the launch the plan is for (the fused 4096-wide kernels only pay off with more than one: 1536 workgroups of
+// 1024 threads leave the tail of a single image on a few CUs -- measured 0.85 vs 0.82 ms per 4K round trip)
+ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi, int n) {
     const int l = ilog2i(PH);
     ColPlan p;
     p.fused_fwd = false;
     if (c->fuse && c->cols_force_log_n1 < 0 && l >= 7 &&
-        ((PWi == 2048 && l - 3 <= 10) || (PWi == 4096 && c->fuse_wide && l - 3 <= 9))) {
+        ((PWi == 2048 && l - 3 <= 10) || (PWi == 4096 && l - 3 <= 9 && (c->fuse_wide >= 2 || (c->fuse_wide == 1 && n >= 2))))) {
         // rows + first column step in one kernel (k_rowcol_fwd): PH = 8 * N2.  2048 wide: one wave per row; 4096 wide: two waves
-        // per row, 1024-thread workgroups (TFFT_FUSE_WIDE=0: the three-pass plan)
+        // per row, 1024-thread workgroups, for launches of two or more images (TFFT_FUSE_WIDE=0: never, 2: always)
         p.direct = false; p.log_n1 = 3; p.log_n2 = l - 3; p.fused_fwd = true;
         return p;
     }
@@ -183,7 +185,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     const float2 *tw_w, *tw_h;
     int rc = get_twiddles(c, s.PWi, &tw_w); if (rc) return rc;
     rc = get_twiddles(c, s.PH, &tw_h); if (rc) return rc;
-    const ColPlan pl = plan_cols(c, s.PH, s.PWi);
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi, n);
     const int N1 = 1 << pl.log_n1, N2 = 1 << pl.log_n2;
     float2 *spec = c->spec(s0), *tmp = c->tmp(s0);
     ColParams cp{};
@@ -555,12 +557,12 @@ int tfft_sync(tfft_ctx* c) {
 
 int tfft_last_hip_error(const tfft_ctx* c) { return c ? c->last_hip : 0; }
 
-int tfft_plan_info(const tfft_ctx* c, int w, int h, int info[4]) {
-    if (!c || !info || w < 1 || h < 1) return TFFT_E_INVALID;
+int tfft_plan_info(const tfft_ctx* c, int w, int h, int n_images, int info[4]) {
+    if (!c || !info || w < 1 || h < 1 || n_images < 1) return TFFT_E_INVALID;
     int pw = next_pow2(w), ph = next_pow2(h);
     if (pw < 2) pw = 2;
     if (pw > TFFT_MAX_DIM || ph > TFFT_MAX_DIM) return TFFT_E_TOO_LARGE;
-    const ColPlan p = plan_cols(c, ph, pw);
+    const ColPlan p = plan_cols(c, ph, pw, n_images);
     info[0] = p.direct ? 1 : 0; info[1] = p.log_n1; info[2] = p.log_n2; info[3] = p.fused_fwd ? 1 : 0;
     return TFFT_OK;
 }
@@ -826,7 +828,7 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
     if (c->tile_read && n_bits > 0 && (g >= 8 || c->tile_read >= 2)) {
         // The spectrum is only ever read at the bins of the list: bucket them by column tile and let the final
         // forward column step read the bits out of its LDS-resident tiles -- no spectrum store, no k_read.
-        const ColPlan pl = plan_cols(c, s.PH, s.PWi);
+        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
         const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16, nb = 3 * ntiles * G;
         rc = ensure_buckets(c, which, n_bits, nb);
         if (rc) return rc;
@@ -1157,7 +1159,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     const Slot& s = c->slots[0];
     if (s.PH == 0) return TFFT_E_STATE;
     for (int i = 1; i < n_images; i++) c->slots[i] = s;
-    const ColPlan pl = plan_cols(c, s.PH, s.PWi);
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi, n_images);
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;

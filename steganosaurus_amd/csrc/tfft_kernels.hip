@@ -308,18 +308,31 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const ui
         }
     }
     __syncthreads();                    // the twiddle table and every live row are staged
-    {
+    // pass twiddles are read at the point of use from the LDS copy: prefetching them into registers
+    // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
+    if constexpr (T == 64) {            // one wave per row: the waves of padded rows skip the transform altogether
+        if (live) {
+            float2 u[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+            WaveSync::sync();
+            fft_block_lazy<M, E, +1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = u[m];      // Z = FFT of the packed (even, odd) row
+        } else {
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = make_float2(0.f, 0.f);
+        }
+    } else {                            // two waves per row: everybody meets at the exchange barriers, padded rows compute nothing
         float2 u[E];
         if (live) {
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
         }
         Sync::sync();
-        // pass twiddles are read at the point of use from the LDS copy: prefetching them into registers
-        // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
         fft_block_lazy<M, E, +1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
 #pragma unroll
-        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);      // Z = FFT of the packed (even, odd) row
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);
     }
     __syncthreads();
 
@@ -437,22 +450,32 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
     __syncthreads();
     const bool live = y < P.H;          // wave uniform (a row is one or two whole waves)
-    if (T == 64 && !live) return;       // one wave per row: no workgroup barrier follows
-
-    Sync::sync();
-    float2 u[E];
-    if (live) {
+    if constexpr (T == 64) {            // one wave per row: no workgroup barrier follows, padded rows are done
+        if (!live) return;
+        WaveSync::sync();
+        float2 u[E];
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
-    }
-    Sync::sync();
-    fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
-    if (live) {
+        WaveSync::sync();
+        fft_block_lazy<M, E, -1, WaveSync>(u, lds, lay, t, n1, ltw, 1);
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
+        WaveSync::sync();
+    } else {                            // two waves per row: padded rows stay for the exchange barriers and compute nothing
+        float2 u[E];
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+        }
+        Sync::sync();
+        fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
+        }
+        Sync::sync();
+        if (!live) return;
     }
-    Sync::sync();
-    if (!live) return;
 
     // ---- quantise and store this plane's bytes of row y
     uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;

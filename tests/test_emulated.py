@@ -70,8 +70,12 @@ def test_columns_of_512_with_lds_twiddles(emu, orc):
 def test_fused_rows_plus_column_step_4096_wide(emu, orc):
     # PW = 4096 and 128 <= PH <= 4096: the same fused kernels with two waves per row (workgroup barriers inside the row transform,
     # which the waves of padded rows sit out): live rows only in the first rows of a workgroup, odd width, centring
-    PC.check_forward_against_oracle(emu, orc, [(2500, 130), (4095, 200)], centers=(0, 1))
-    PC.check_identity_roundtrip(emu, [(3000, 140), (4096, 128)])
+    os.environ["TFFT_FUSE_WIDE"] = "2"          # also for single images (the default keeps them on the three-pass plan)
+    try:
+        PC.check_forward_against_oracle(emu, orc, [(2500, 130), (4095, 200)], centers=(0, 1))
+        PC.check_identity_roundtrip(emu, [(3000, 140), (4096, 128)])
+    finally:
+        del os.environ["TFFT_FUSE_WIDE"]
 
 
 def test_identity_roundtrip(emu):

@@ -604,3 +604,58 @@ def test_graph_replay_matches_plain_launches(lib, orc):
     for a, b in zip(res["4"], res["0"]):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_wide_fused_plan_against_oracle_and_audit(lib, orc):
+    """The two-pass plan for 4096-wide images (fused row+column kernels with two waves per row, 512-long second column step),
+    which launches of two or more images take: forced here for single images so that the full-size oracle and audit checks run
+    through it -- 3840x2160 embed/extract against the oracle, the fp32 spectrum against the fp64 audit transform with and without
+    centring, odd widths, and the exact forward -> inverse identity."""
+    os.environ["TFFT_FUSE_WIDE"] = "2"
+    try:
+        ctx = B.Context(3840, 2160, lib=lib)
+        assert ctx.plan_info(3840, 2160, 1)["fused"] and ctx.plan_info(3840, 2160, 1)["log_n2"] == 9
+        ctx.close()
+        r = PC.check_embed_extract(lib, orc, 3840, 2160, n_stream_bits(32768), dict())
+        assert abs(r["ber_gpu"] - r["ber_ref"]) < 0.01, r
+        for i, (w, h) in enumerate([(3840, 2160), (4096, 4096), (2131, 1179), (2049, 127), (4095, 300)]):
+            PC.check_product_against_audit64(lib, w, h, center=bool(i & 1), seed=200 + i)
+        PC.check_identity_roundtrip(lib, [(3840, 2160), (4096, 4096), (2049, 127), (4095, 129), (3000, 2600)])
+    finally:
+        del os.environ["TFFT_FUSE_WIDE"]
+    ctx = B.Context(3840, 2160, lib=lib)
+    assert not ctx.plan_info(3840, 2160, 1)["fused"] and ctx.plan_info(3840, 2160, 2)["fused"] and ctx.plan_info(1920, 1080, 1)["fused"]
+    ctx.close()
+
+
+def test_wide_fused_batch_equals_forced_single(lib, orc):
+    """A launch of 3 images of 3840x2160 (two-pass plan by default) returns, image by image, what the single-image calls return
+    when they are forced onto the same plan."""
+    import torch
+    w, h, nimg, n = 3840, 2160, 3, 50000
+    imgs = np.stack([cover_rgb(w, h, 80 + i) for i in range(nimg)])
+    bits = np.random.default_rng(8).integers(0, 2, (nimg, n)).astype(np.uint8)
+    bins = B.Walk(orc.subkeys(PC.PK)[0], 4096, 4096, lib=lib).next(n)
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(imgs).to(dev); d_bits = torch.from_numpy(bits).to(dev)
+    d_bins = torch.from_numpy(bins.view(np.uint8).reshape(-1, 8).copy()).to(dev)
+    d_out = torch.empty_like(d_img); d_raw = torch.zeros((nimg, n), dtype=torch.uint8, device=dev); d_us = torch.zeros(nimg, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx = B.Context(w, h, slots=nimg, lib=lib)
+    ctx.embed_batch_dev(nimg, d_img.data_ptr(), w, h, d_bins.data_ptr(), d_bits.data_ptr(), n, d_out.data_ptr(), usable_ptr=d_us.data_ptr())
+    ctx.extract_batch_dev(nimg, d_out.data_ptr(), w, h, d_bins.data_ptr(), n, d_raw.data_ptr())
+    ctx.sync(); ctx.close()
+    os.environ["TFFT_FUSE_WIDE"] = "2"
+    try:
+        one = B.Context(w, h, lib=lib)
+    finally:
+        del os.environ["TFFT_FUSE_WIDE"]
+    for i in range(nimg):
+        one.forward_rgb8(imgs[i])
+        assert one.capacity(0.01 * one.medians()) == int(d_us[i].item())
+        one.embed_bins(bins, bits[i])
+        st = one.inverse_rgb8(w, h)
+        assert np.array_equal(st, d_out[i].cpu().numpy()), i
+        one.forward_rgb8(st)
+        assert np.array_equal(one.read_bins(bins), d_raw[i].cpu().numpy()), i
+    one.close()
