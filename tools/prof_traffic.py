@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/prof_traffic.py <summary.json> <workload> [traffic.json] -- HBM bytes per launch per bench stage
+"""tools/prof_traffic.py <summary.json> <workload> <source tag> [traffic.json] -- HBM bytes per launch per bench stage
 from the PMC means of tools/prof_summary.py: (2*FETCH_SIZE + WRITE_SIZE) KiB (FETCH_SIZE doubled on gfx950,
-MI355X_MICROARCH.md, HBM/rocprofv3 section).  Stages made of several kernels sum their kernels
-(launches per stage given below).  Updates profiles/traffic.json in place."""
-import json, os, sys
+MI355X_MICROARCH.md, HBM/rocprofv3 section; calibrated on these kernels' own compulsory byte counts).  Stages made of
+several kernels sum their kernels.  Updates profiles/traffic.json in place (one entry per workload + where it came from)."""
+import json, os, re, sys
 
-summary, workload = sys.argv[1], sys.argv[2]
-out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
+summary, workload, source = sys.argv[1], sys.argv[2], sys.argv[3]
+out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
 S = json.load(open(summary))
 
 
@@ -17,41 +17,39 @@ def kib(name):
     return 2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
 
 
-def first(*names):
-    for n in names:
-        b = kib(n)
-        if b is not None:
-            return b
-    return None
+def match(pattern):
+    """the busiest kernel (by share of the run) whose name matches"""
+    best = None
+    for name, v in S.items():
+        if re.match(pattern, name) and kib(name) is not None and (best is None or v["pct"] > S[best]["pct"]):
+            best = name
+    return (kib(best), best) if best else (None, None)
 
 
-def prefix(*prefixes):
-    """first kernel (template arguments after the prefix ignored: DC / TW switches) that has counters"""
-    for p in prefixes:
-        for name in S:
-            if name.startswith(p):
-                b = kib(name)
-                if b is not None:
-                    return b
-    return None
-
-
-stages = {
-    "rows_fwd": first("k_rowcol_fwd<3>", "k_rows_fwd<11, 1>", "k_rows_fwd<12, 1>", "k_rows_fwd<10, 3>"),
-    "rows_inv": first("k_colrow_inv<3>", "k_rows_inv<11, 1>", "k_rows_inv<12, 1>", "k_rows_inv<10, 3>"),
-    "cols_fwd_b": prefix("k_fft_cols<8, 1, 0", "k_fft_cols<6, 1, 0", "k_fft_cols<7, 1, 0"),
-    "cols_fwd_read": prefix("k_fft_cols<8, 1, 2", "k_fft_cols<6, 1, 2", "k_fft_cols<7, 1, 2", "k_fft_cols<8, 1, 1", "k_fft_cols<6, 1, 1", "k_fft_cols<7, 1, 1"),
-    "cols_inv_a": prefix("k_fft_cols<8, -1, 0", "k_fft_cols<6, -1, 0", "k_fft_cols<7, -1, 0"),
-    "embed": kib("k_embed"),
-    "read": kib("k_read"),
-    "capacity": first("k_capacity<false>", "k_capacity<true>"),
-}
-med = [kib(k) for k in ("k_collect_bracket",)] + [2 * (kib("k_hist_spec") or 0), kib("k_hist_cand<true>") or 0]
-if med[0] is not None:
-    stages["medians"] = sum(med)
+stages, kernels = {}, {}
+for stage, pat in {
+    "rows_fwd": r"k_rowcol_fwd<|k_rows_fwd<",
+    "rows_inv": r"k_colrow_inv<|k_rows_inv<",
+    "cols_fwd_a": r"k_fft_cols<\d+, 1, 0, false, true>",                 # first forward column step (output twiddles)
+    "cols_fwd_b": r"k_fft_cols<\d+, 1, 0, (true|false), false>",         # final forward column step
+    "cols_fwd_read": r"k_fft_cols<\d+, 1, [12], ",                       # the same step as extraction runs it
+    "cols_inv_a": r"k_fft_cols<\d+, -1, 0, (true|false), true>",         # first inverse column step
+    "cols_inv_b": r"k_fft_cols<\d+, -1, 0, false, false>",               # last inverse column step (three-pass plans)
+    "embed": r"k_embed$", "read": r"k_read$", "capacity": r"k_capacity<",
+}.items():
+    b, name = match(pat)
+    if b is not None:
+        stages[stage] = int(b * 1024)
+        kernels[stage] = name
+med = [kib(k) for k in S if k.startswith("k_collect_bracket")] + [2 * (kib("k_hist_spec") or 0), kib("k_hist_cand<true>") or 0]
+if med and med[0] is not None:
+    stages["medians"] = int(sum(med) * 1024)
 T = json.load(open(out)) if os.path.exists(out) else {}
-T[workload] = {k: int(v * 1024) for k, v in stages.items() if v is not None}
-T["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
-              "`bench.py --batched-only` (tools/prof.sh, tools/prof_traffic.py); the per-kernel means are in profiles/r1/*_pmc_summary.json")
+T[workload] = stages
+T.setdefault("_kernels", {})[workload] = kernels
+T.setdefault("_source", {})[workload] = source
+T["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of `bench.py --batched-only "
+              "--workload <w>` (tools/prof.sh, tools/prof_traffic.py); per-kernel means in profiles/<round>/*_pmc_summary.json.  bench.py "
+              "replays these numbers as roofline.traffic and says so")
 json.dump(T, open(out, "w"), indent=1)
-print(json.dumps(T[workload], indent=1))
+print(json.dumps(stages, indent=1))
