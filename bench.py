@@ -243,7 +243,10 @@ def profile_stages(wl, reps):
         kb = kernel_bytes(name, wl.W, wl.H, nb, nb, wl.plan) * slots
         stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots, "bytes": kb,
                         "GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
-                        "frac": round(kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+                        "frac": round(kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                        "pmc_traffic_bytes": load_traffic(wl.name, name)[0]}       # replayed from profiles/traffic.json (None: not captured)
+        if name in ("embed", "read"):
+            stages[name]["note"] = "scatter / gather of 8-byte bins: `bytes` are the bins themselves, the hardware moves whole 32/64-byte sectors (3-4x, see pmc_traffic_bytes)"
         if wl.plan["fused"] and name in ("rows_fwd", "rows_inv"):
             stages[name]["kernel"] = "rows + column step A fused" if name == "rows_fwd" else "column step B' + rows fused"
     return stages
