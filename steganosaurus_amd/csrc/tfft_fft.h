@@ -15,24 +15,80 @@
 
 namespace tfft {
 
+// Complex arithmetic on native 2-vectors: (re, im) stays ONE 64-bit register pair through the optimiser, so an add is one
+// v_pk_add_f32, a multiply by a complex constant one v_pk_mul_f32 + one v_pk_fma_f32, and a multiplication by +-i only a source
+// swizzle (op_sel / neg) of whatever consumes it.  Written component by component (make_float2(a.x + b.x, ...)) the vectoriser
+// paired components of DIFFERENT values and patched the pairs back together with v_mov_b32: 22 % of the VALU instructions of the
+// fused row+column kernels, which are VALU bound.  TFFT_NATIVE_V2 is set by hipcc only; the CPU emulation of the tests (g++) takes
+// the scalar forms.
+#if defined(__HIPCC__) && !defined(TFFT_SCALAR_COMPLEX)
+#define TFFT_NATIVE_V2 1
+typedef float tfft_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tfft_v2 nv(float2 a) { return tfft_v2{a.x, a.y}; }
+__device__ __forceinline__ float2 f2(tfft_v2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return f2(nv(a) + nv(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return f2(nv(a) - nv(b)); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    const tfft_v2 bs = tfft_v2{-b.y, b.x};                    // i*b
+    return f2(a.x * nv(b) + a.y * bs);
+}
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return f2(nv(a) * s); }
+__device__ __forceinline__ float2 cmuli(float2 a) { return f2(tfft_v2{-a.y, a.x}); }      // i*a
+#else
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float2 cmuli(float2 a) { return make_float2(-a.y, a.x); }
+#endif
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// Real-input FFT of length 2M through a complex FFT of length M on z[m] = x[2m] + i x[2m+1]:
+//   forward: Z[k], Z[M-k], w = exp(+2 pi i k/2M)  ->  X[k] = Ev + w Od,  X[M-k] = conj(Ev - w Od)
+//            Ev = (Z[k] + conj Z[M-k])/2,  Od = (Z[k] - conj Z[M-k])/(2i)
+//   inverse: X[k], X[M-k], w                      ->  Z[k] = Ev + i Od,  Z[M-k] = conj(Ev - i Od)
+//            Ev = (X[k] + conj X[M-k])/2,  Od = (X[k] - conj X[M-k])/2 * conj(w)
+__device__ __forceinline__ void rsplit_fwd(float2 zk, float2 zm, float2 w, float2& xk, float2& xmk) {
+    const float2 czm = cconj(zm);
+    const float2 ev = cscale(cadd(zk, czm), 0.5f);
+    const float2 od = cscale(cmuli(csub(zk, czm)), -0.5f);
+    const float2 b = cmul(w, od);
+    xk = cadd(ev, b);
+    xmk = cconj(csub(ev, b));
+}
+__device__ __forceinline__ void rsplit_inv(float2 xk, float2 xm, float2 w, float2& zk, float2& zmk) {
+    const float2 cxm = cconj(xm);
+    const float2 ev = cscale(cadd(xk, cxm), 0.5f);
+    const float2 iod = cmuli(cmul(cscale(csub(xk, cxm), 0.5f), cconj(w)));
+    zk = cadd(ev, iod);
+    zmk = cconj(csub(ev, iod));
+}
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 constexpr int bitrev(int v, int bits) { return bits == 0 ? 0 : ((v & 1) << (bits - 1)) | bitrev(v >> 1, bits - 1); }
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-// d * exp(SIGN * 2*pi*i * idx16/16), idx16 in 0..7 (compile-time after unrolling)
+// d * exp(SIGN * 2*pi*i * idx16/16), idx16 in 0..7 (compile-time after unrolling): alpha*d + beta*(SIGN*i*d)
 template <int SIGN>
 __device__ __forceinline__ float2 twmul16(float2 d, int idx16) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
     constexpr float s = (float)SIGN;
+#ifdef TFFT_NATIVE_V2
+    const tfft_v2 dv = nv(d), rot = tfft_v2{-s * d.y, s * d.x};
+    switch (idx16) {
+        case 0: return d;
+        case 1: return f2(C1 * dv + S1 * rot);
+        case 2: return f2((dv + rot) * H);
+        case 3: return f2(S1 * dv + C1 * rot);
+        case 4: return f2(rot);
+        case 5: return f2(C1 * rot - S1 * dv);
+        case 6: return f2((rot - dv) * H);
+        default: return f2(S1 * rot - C1 * dv);
+    }
+#else
     switch (idx16) {
         case 0: return d;
         case 1: return make_float2(d.x * C1 - s * d.y * S1, s * d.x * S1 + d.y * C1);
@@ -43,6 +99,7 @@ __device__ __forceinline__ float2 twmul16(float2 d, int idx16) {
         case 6: return make_float2((-d.x - s * d.y) * H, (s * d.x - d.y) * H);
         default: return make_float2(-d.x * C1 - s * d.y * S1, s * d.x * S1 - d.y * C1);
     }
+#endif
 }
 
 // In-register radix-2 DIF network on v[OFF .. OFF+R): result X[q] lands in

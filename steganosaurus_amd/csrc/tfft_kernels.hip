@@ -210,15 +210,13 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
         if (k > M / 2) break;
         const int k2 = (M - k) & (M - 1);
         const float2 zk = lds[lay.idx(k, pb)], zm = lds[lay.idx(k2, pb)];
-        const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // Ev[k]
-        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                        // zk - conj(zm)
-        const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);                        // Od[k] = d/(2i)
-        const float2 b = cmul(wk[j], od);
+        float2 xk, xmk;
+        rsplit_fwd(zk, zm, wk[j], xk, xmk);
         if (k == 0) {
-            dst[0] = make_float2(a.x + b.x, a.x - b.x);      // X[0] and X[M], both real, packed
+            dst[0] = make_float2(xk.x, xmk.x);               // X[0] = Ev + Od and X[M] = Ev - Od (w = 1), both real, packed
         } else {
-            dst[k] = cadd(a, b);
-            if (k2 != k) dst[k2] = cconj(csub(a, b));
+            dst[k] = xk;
+            if (k2 != k) dst[k2] = xmk;
         }
     }
 }
@@ -351,14 +349,9 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const ui
 #pragma unroll
     for (int r = 0; r < N1; r++) {
         const float2 zk = lds[lay.idx(xa, r)], zm = lds[lay.idx((M - xa) & (M - 1), r)];
-        const float2 a = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // Ev[x]
-        const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                        // zk - conj(zm)
-        const float2 od = make_float2(0.5f * d.y, -0.5f * d.x);                        // Od[x] = d/(2i)
-        const float2 b = cmul(wsx, od);
-        va[r] = cadd(a, b);
-        vb[r] = cconj(csub(a, b));
+        rsplit_fwd(zk, zm, wsx, va[r], vb[r]);
         if (px == 0) {
-            va[r] = make_float2(a.x + b.x, a.x - b.x);                                 // X[0] and X[M], both real, packed
+            va[r] = make_float2(va[r].x, vb[r].x);                                     // X[0] and X[M] (w = 1), both real, packed
             const float2 zh = lds[lay.idx(M / 2, r)];                                  // column M/2 pairs with itself
             const float2 ah = make_float2(zh.x, 0.0f), dh = make_float2(0.0f, 2.0f * zh.y);
             const float2 odh = make_float2(0.5f * dh.y, -0.5f * dh.x);
@@ -439,11 +432,10 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
             const float2 od = cmul(make_float2(0.0f, xm.y), cconj(wsh));                       // column M/2 pairs with itself
             lds[lay.idx(M / 2, r)] = make_float2(xm.x - od.y, 0.0f + od.x);
         } else {
-            const float2 ev = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
-            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
-            const float2 od = cmul(d, cconj(wsx));
-            lds[lay.idx(xa, r)] = make_float2(ev.x - od.y, ev.y + od.x);
-            lds[lay.idx(xb, r)] = make_float2(ev.x + od.y, od.x - ev.y);
+            float2 za, zb;
+            rsplit_inv(xk, xm, wsx, za, zb);
+            lds[lay.idx(xa, r)] = za;
+            lds[lay.idx(xb, r)] = zb;
         }
     }
 #pragma unroll
@@ -536,13 +528,11 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
         const int k = t + j * T;
         if (k <= M / 2) {
             const int k2 = (M - k) & (M - 1);
-            const float2 ev = make_float2(0.5f * (xk[j].x + xm[j].x), 0.5f * (xk[j].y - xm[j].y));
-            const float2 d = make_float2(0.5f * (xk[j].x - xm[j].x), 0.5f * (xk[j].y + xm[j].y));
-            const float2 od = cmul(d, cconj(wk[j]));
-            float2 zk = make_float2(ev.x - od.y, ev.y + od.x);
+            float2 zk, zk2;
+            rsplit_inv(xk[j], xm[j], wk[j], zk, zk2);
             if (k == 0) zk = make_float2(0.5f * (xk[j].x + xk[j].y), 0.5f * (xk[j].x - xk[j].y));     // X[0], X[M] packed in bin 0
             lds[lay.idx(k, pb)] = zk;
-            if (k2 != k) lds[lay.idx(k2, pb)] = make_float2(ev.x + od.y, od.x - ev.y);
+            if (k2 != k) lds[lay.idx(k2, pb)] = zk2;
         }
     }
     Sync::sync();
@@ -701,6 +691,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     constexpr bool TWL = (LOGL >= TFFT_COLS_LDS_TW_LOG);
     float2 W[TWL ? 1 : tw_regs<L, E>()];
     float2* lds_tw = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * (C + (DC ? 1 : 0) + (TW ? 1 : 0));
+    float2* lds_aw = lds_tw + (TWL ? L : 0) + gl * C;      // COLS_READ with DC: the current tile's 16 column factors
     if (TWL) {
         const int tws = P.PH >> LOGL;
         for (int k = (gl * T + t) * C + c; k < L; k += blockDim.z * T * C) lds_tw[k] = tw[k * tws];
@@ -725,12 +716,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
             __syncthreads();            // the last gather of fft_block has been consumed by every thread
-            if (DC) {
-#pragma unroll
-                for (int m = 0; m < E; m++) u[m] = cadd(u[m], cmul(lds_ah[t + m * T], awc));
-            }
 #pragma unroll
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
+            // DC removal: the rank-1 term is added to the bins that are READ (a few hundred per tile), not to all 16 x L values of
+            // the tile (that was 0.056 ms of the 0.50 ms launch): the tile's 16 column factors go to LDS beside the row factors
+            if (DC && t == 0) lds_aw[c] = awc;
             __syncthreads();
             if (g < P.G) {
                 const unsigned b = (unsigned)((plane * P.G + g) * ntiles + tile);
@@ -740,6 +730,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                 for (unsigned e = e0 + tid; e < e1; e += nthr) {
                     const TileBin tb = P.rd_bins[e];
                     float2 v = lds[lay.idx(tb.k, tb.c)];
+                    if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
                     if (tb.conj) v = cconj(v);
                     bo[tb.bit] = (uint8_t)(P.rd_generic ? read_bit_value(v, *P.rd_ep, plane, P.rd_jitter, tb.bit) : (v.y >= 0.0f ? 1 : 0));
                 }
@@ -1785,7 +1776,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
     const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
-                       (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0);
+                       (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0) + ((MODE == COLS_READ && DC) ? (size_t)gpb * C * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
