@@ -244,7 +244,7 @@ def profile_stages(wl, reps):
         stages[name] = {"ms": round(ms, 5), "launches": nl, "images_per_launch": slots, "bytes": kb,
                         "GBs": round(kb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                         "frac": round(kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
-                        "pmc_traffic_bytes": load_traffic(wl.name, name)[0]}       # replayed from profiles/traffic.json (None: not captured)
+                        "pmc_traffic_bytes": load_traffic(wl.name, name, slots)[0]}       # replayed from profiles/traffic.json (None: not captured)
         if name in ("embed", "read"):
             stages[name]["note"] = "scatter / gather of 8-byte bins: `bytes` are the bins themselves, the hardware moves whole 32/64-byte sectors (3-4x, see pmc_traffic_bytes)"
         if wl.plan["fused"] and name in ("rows_fwd", "rows_inv"):
@@ -252,10 +252,14 @@ def profile_stages(wl, reps):
     return stages
 
 
-def load_traffic(workload, stage):
+def load_traffic(workload, stage, images_per_launch=None):
+    """PMC bytes per launch captured by an earlier rocprofv3 run of the same command (tools/round_profiles.sh); only replayed
+    when a launch of this run covers as many images as a launch of that one"""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(tf))
+        if images_per_launch is not None and t.get("_images_per_launch", {}).get(workload) != images_per_launch:
+            return None, None
         v = t.get(workload, {}).get(stage)
         src = t.get("_source", {}).get(workload)
         return v, src
@@ -267,7 +271,7 @@ def roofline_of(wl, stages, reps):
     fft = {k: v for k, v in stages.items() if k.startswith(("rows", "cols"))}
     dom = max(fft, key=lambda k: fft[k]["ms"])
     d = stages[dom]
-    traffic, src = load_traffic(wl.name, dom)
+    traffic, src = load_traffic(wl.name, dom, d["images_per_launch"])
     sm_e, sm_x = survey_model_bytes(wl.W, wl.H, wl.n_bits)
     return {"bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
             "traffic": traffic,

@@ -48,6 +48,11 @@ T = json.load(open(out)) if os.path.exists(out) else {}
 T[workload] = stages
 T.setdefault("_kernels", {})[workload] = kernels
 T.setdefault("_source", {})[workload] = source
+try:      # the counters are per launch: remember how many images a launch of that run covered
+    bt = json.load(open(os.path.join(os.path.dirname(summary), "bench_trace.json")))
+    T.setdefault("_images_per_launch", {})[workload] = bt["config"]["images_per_launch"]
+except Exception:
+    pass
 T["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of `bench.py --batched-only "
               "--workload <w>` (tools/prof.sh, tools/prof_traffic.py); per-kernel means in profiles/<round>/*_pmc_summary.json.  bench.py "
               "replays these numbers as roofline.traffic and says so")
