@@ -95,6 +95,7 @@ struct tfft_ctx {
 #endif
     int graph_max_images = 4;             // TFFT_GRAPHS=0 disables; larger calls are bandwidth bound and gain nothing
     int stats_fused = 1;                  // TFFT_STATS_FUSED=0: capacity as its own pass after the medians (A/B)
+    int stats_compact = 1;                // TFFT_STATS_COMPACT=0: the 16-launch statistics pipeline also for small planes (A/B)
     int fuse = 1;
     int fuse_wide = 1;
 
@@ -356,7 +357,7 @@ int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams*
     unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
                              c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st,
-                             cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable));
+                             cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable, c->stats_compact));
     return TFFT_OK;
 }
 
@@ -485,6 +486,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
     if (const char* e = getenv("TFFT_MEDIAN_FALLBACK")) c->median_force_fallback = atoi(e);
     if (const char* e = getenv("TFFT_STATS_FUSED")) c->stats_fused = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
@@ -509,6 +511,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
     if (!rc) rc = dev_alloc(c, (void**)&c->last_row, 2 * sizeof(int));
     if (!rc && hipMemset(c->err, 0, sizeof(int)) != hipSuccess) rc = TFFT_E_HIP;
+    if (!rc && hipMemset(c->sel, 0, ns * 3 * sizeof(SelectState)) != hipSuccess) rc = TFFT_E_HIP;      // the compact statistics pipeline starts from clean histograms
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = TFFT_E_HIP;
     if (rc != TFFT_OK) { tfft_destroy(c); return rc; }
     *out = c;
@@ -611,7 +614,7 @@ int tfft_median_path(tfft_ctx* c, int slot, int fast[3]) {
     if (!h) return TFFT_E_NOMEM;
     hipError_t e = hipMemcpyAsync(h, c->sel + 3 * slot, 3 * sizeof(SelectState), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 3; i++) fast[i] = (h[i].done == 1) ? 1 : 0;
+    for (int i = 0; i < 3; i++) fast[i] = (h[i].done == 1 && h[i].fast) ? 1 : 0;
     free(h);
     if (e != hipSuccess) { c->last_hip = (int)e; return TFFT_E_HIP; }
     return TFFT_OK;
@@ -1163,7 +1166,11 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
-    if (stage == MEDIANS) launches = (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);      // fused: + settle + the guarded recount
+    {
+        const bool compact = c->stats_compact && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
+        if (stage == MEDIANS) launches = compact ? (c->median_force_fallback ? 2 : 5) + (c->stats_fused ? 1 : 0)
+                                                 : (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);
+    }
     if (stage == CAPACITY) launches = c->stats_fused ? 0 : 2;      // fused: counted inside the medians' full pass
     const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
     if (n_launches) *n_launches = launches;

@@ -134,7 +134,8 @@ hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* ji
 // partial = [n_images*3*TFFT_STAT_MAX_BLOCKS] block counts, amb = [n_images*3*TFFT_AMB_CAP] parked |F|^2, usable[n_images]
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident, hipStream_t s,
-                          const CapParams* cap = nullptr, unsigned* partial = nullptr, float* amb = nullptr, unsigned long long* usable = nullptr);
+                          const CapParams* cap = nullptr, unsigned* partial = nullptr, float* amb = nullptr, unsigned long long* usable = nullptr,
+                          int compact = 1);
 int collect_bracket_resident_blocks();
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s, const unsigned* only_flagged = nullptr);

@@ -1098,7 +1098,9 @@ __global__ void k_select_init(SelectState* __restrict__ st, unsigned long long r
 }
 
 // ---- fast path ----------------------------------------------------------------------------------
-__global__ void k_select_guess(SelectState* __restrict__ st, double magmin) {
+// Also resets the per-call fields (the histogram itself is left zero by whatever kernel used it last: every select kernel cleans
+// up behind itself, and the context zeroes the state once at creation), so the compact pipeline needs no k_select_init launch.
+__global__ void k_select_guess(SelectState* __restrict__ st, double magmin, unsigned long long rank) {
     unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
     SelectState* s = st + blockIdx.x;
     stage_hist(s, h, 4096);
@@ -1113,6 +1115,7 @@ __global__ void k_select_guess(SelectState* __restrict__ st, double magmin) {
     if (threadIdx.x == 0) {
         const unsigned lo = (unsigned)(b > 0 ? b - 1 : 0), hi = (unsigned)(b < 4095 ? b + 1 : 4095);
         s->lo = lo; s->hi = hi;
+        s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f;
         if (magmin >= 0.0) {
             // the median's |F|^2 lies in [bits(lo<<19), bits((hi+1)<<19)); sqrtf and mag2_threshold are monotone, so the capacity
             // threshold T2 = mag2_threshold(magmin * sqrtf(.)) lies in [t2_lo, t2_hi]
@@ -1300,9 +1303,12 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
 
 // usable[img] = sum_p floor(c_p / 2) from the bracket pass: c_p = the blocks' definite counts + the parked values that reach
 // T2 = mag2_threshold(magmin * median_p).  One block of three waves per image.  When a plane's median came from the fallback
-// select (its bracket was wrong) or it parked more than TFFT_AMB_CAP values, flag[img] = 1: k_capacity recounts that image.
+// select (its bracket was wrong) or it parked more than TFFT_AMB_CAP values the image cannot be settled: flag[img] = 1 and
+//   recount = 0: k_capacity recounts it (guarded launches behind this one);
+//   recount = 1: this block recounts it itself over the annulus box (rare and slow: one block per image).
 __global__ void k_capacity_settle(const SelectState* __restrict__ st, const float* __restrict__ med, double magmin, const unsigned* __restrict__ partial,
-                                  int nb, const float* __restrict__ amb, unsigned long long* __restrict__ usable, unsigned* __restrict__ flag) {
+                                  int nb, const float* __restrict__ amb, unsigned long long* __restrict__ usable, unsigned* __restrict__ flag,
+                                  const float2* __restrict__ spec, CapParams P, int recount) {
     unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3] + bad
     unsigned* bad = reinterpret_cast<unsigned*>(c + 3);
     const int img = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1319,7 +1325,34 @@ __global__ void k_capacity_settle(const SelectState* __restrict__ st, const floa
     for (unsigned i = lane; i < n_amb && i < TFFT_AMB_CAP; i += 64) if (!(av[i] < t2)) a++;
     if (a) atomicAdd(&c[p], a);
     __syncthreads();
-    if (threadIdx.x == 0) { usable[img] = c[0] / 2 + c[1] / 2 + c[2] / 2; flag[img] = bad[0]; }
+    const bool redo = bad[0] != 0;
+    if (redo && recount) {              // block uniform
+        __syncthreads();
+        if (threadIdx.x < 3) c[threadIdx.x] = 0;
+        __syncthreads();
+        const int M = P.PWi >> 1;
+        for (int q = 0; q < 3; q++) {
+            const float tq = mag2_threshold(magmin * (double)med[img * 3 + q]);
+            const float2* pl = spec + (size_t)img * P.img_stride + (size_t)q * P.PH * M;
+            unsigned long long mine = 0;
+            for (int y = 1; y < P.bh; y++) {
+                if (2 * y == P.PH) continue;
+                const unsigned long long yy = (unsigned long long)y * (unsigned long long)y;
+                const float2* row = pl + (size_t)y * M;
+                const float2* mrow = pl + (size_t)((P.PH - y) & (P.PH - 1)) * M;
+                for (int x = 1 + (int)threadIdx.x; x < P.bw; x += (int)blockDim.x) {
+                    if (2 * x == P.PW) continue;
+                    const unsigned long long r2 = yy + (unsigned long long)x * (unsigned long long)x;
+                    if (r2 < P.s_lo || r2 > P.s_hi) continue;
+                    const float2 v = x < M ? row[x] : mrow[P.PW - x];
+                    if (!(mag2_of(v) < tq)) mine++;
+                }
+            }
+            if (mine) atomicAdd(&c[q], mine);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { usable[img] = c[0] / 2 + c[1] / 2 + c[2] / 2; flag[img] = (redo && !recount) ? 1u : 0u; }
 }
 
 // LEVEL 2: verify the bracket and pick the 2048-wide sub-bucket; LEVEL 3: the exact value.
@@ -1379,6 +1412,99 @@ __global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// ---- compact pipeline (planes up to 2^24 bins): the three launches after the bracket pass in one, the six fallback launches
+// in one.  A single image spends its time in the GPU-side latency of dependent launches (~6.7 us each: the statistics were 16 of
+// the ~35 of a 1080p round trip), not in the kernels.
+// Bucket holding `rank` among nb <= 4096 counters in LDS (h zero padded to 4096, p1[256], p2[16], res[4]); any block size >= 256.
+__device__ __forceinline__ void find_bucket_blk(unsigned* h, unsigned* p1, unsigned* p2, unsigned long long* res, unsigned long long rank, int nb,
+                                                int& bucket, unsigned long long& before) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    if (t < 256) { unsigned a = 0; for (int i = 0; i < 16; i++) a += h[t * 16 + i]; p1[t] = a; }
+    __syncthreads();
+    if (t < 16) { unsigned a = 0; for (int i = 0; i < 16; i++) a += p1[t * 16 + i]; p2[t] = a; }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long cum = 0;
+        int g2 = 15; for (int i = 0; i < 16; i++) { if (cum + p2[i] > rank) { g2 = i; break; } cum += p2[i]; }
+        int g1 = g2 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + p1[g2 * 16 + i] > rank) { g1 = g2 * 16 + i; break; } cum += p1[g2 * 16 + i]; }
+        int b = g1 * 16 + 15; for (int i = 0; i < 16; i++) { if (cum + h[g1 * 16 + i] > rank) { b = g1 * 16 + i; break; } cum += h[g1 * 16 + i]; }
+        if (b >= nb) b = nb - 1;
+        res[0] = (unsigned long long)b; res[1] = cum;
+    }
+    __syncthreads();
+    bucket = (int)res[0]; before = res[1];
+}
+// k_select_fast<2> + k_hist_cand<true> + k_select_fast<3> for one plane per block (1024 threads)
+__global__ void __launch_bounds__(1024) k_select_finish(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride,
+                                                        float* __restrict__ med_out, unsigned long long rank) {
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
+    unsigned long long* res = reinterpret_cast<unsigned long long*>(p2 + 16);      // [0..1] find result, [2] total
+    SelectState* s = st + blockIdx.x;
+    const int t = threadIdx.x;
+    for (int i = t; i < 4096; i += blockDim.x) h[i] = (i < 1024) ? s->hist[i] : 0u;
+    if (t == 0) res[2] = 0;
+    __syncthreads();
+    { unsigned long long a = 0; for (int i = t; i < 1024; i += blockDim.x) a += h[i]; if (a) atomicAdd(&res[2], a); }
+    __syncthreads();
+    const unsigned long long total = res[2], below = s->below;
+    const bool ok = !(rank < below || rank - below >= total);       // verifies the bracket: exact result or declared failure
+    for (int i = t; i < 4096; i += blockDim.x) s->hist[i] = 0;        // leave the global histogram clean for whoever comes next
+    if (!ok) {
+        if (t == 0) { s->n_cand = 0; s->prefix = 0; s->done = 0; }  // k_median_fallback takes over
+        return;
+    }
+    int b2; unsigned long long before;
+    find_bucket_blk(h, p1, p2, res, rank - below, 1024, b2, before);
+    const unsigned long long rank3 = rank - below - before;
+    for (int i = t; i < 4096; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const unsigned n = s->n_cand;
+    const unsigned* in = cand + (size_t)blockIdx.x * cand_stride;
+    for (unsigned i = t; i < n; i += blockDim.x) {
+        const unsigned c = in[i], v = c & 0x7FFFFFFFu;
+        if ((v >> 11) == (unsigned)b2) atomicAdd(&h[v & 2047u], (c >> 31) ? 2u : 1u);
+    }
+    int b3;
+    find_bucket_blk(h, p1, p2, res, rank3, 2048, b3, before);
+    if (t == 0) {
+        med_out[blockIdx.x] = sqrtf(__uint_as_float((s->lo << 19) + ((unsigned)b2 << 11) + (unsigned)b3));
+        s->prefix = (unsigned)b2; s->done = 1; s->fast = 1;
+    }
+}
+// The plain three-level radix select (4096 / 1024 / 512 buckets of the float's bits, as k_select<1..3>) by ONE block per plane:
+// three passes of that block over its plane.  Runs only where the fast path did not verify (or when forced): slow and rare.
+__global__ void __launch_bounds__(1024) k_median_fallback(const float2* __restrict__ spec, int PH, int M, size_t img_stride, SelectState* __restrict__ st,
+                                                          float* __restrict__ med_out, unsigned long long rank, int force) {
+    SelectState* s = st + blockIdx.x;
+    if (!force && s->done) return;
+    unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
+    unsigned long long* res = reinterpret_cast<unsigned long long*>(p2 + 16);
+    const int img = blockIdx.x / 3, plane = blockIdx.x - 3 * img, t = threadIdx.x;
+    const float2* pl = spec + (size_t)img * img_stride + (size_t)plane * PH * M;
+    const size_t n = (size_t)PH * M;
+    unsigned prefix = 0;
+    for (int level = 1; level <= 3; level++) {
+        for (int i = t; i < 4096; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        for (size_t e = t; e < n; e += blockDim.x) {
+            const int y = (int)(e / M), x = (int)(e - (size_t)y * M);
+            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) {
+                if (level == 1) atomicAdd(&h[b >> 19], w);
+                else if (level == 2) { if ((b >> 19) == prefix) atomicAdd(&h[(b >> 9) & 1023u], w); }
+                else { if ((b >> 9) == prefix) atomicAdd(&h[b & 511u], w); }
+            });
+        }
+        int b; unsigned long long before;
+        find_bucket_blk(h, p1, p2, res, rank, level == 1 ? 4096 : level == 2 ? 1024 : 512, b, before);
+        rank -= before;
+        prefix = (level == 1) ? (unsigned)b : (level == 2) ? ((prefix << 10) | (unsigned)b) : ((prefix << 9) | (unsigned)b);
+        __syncthreads();
+    }
+    if (t == 0) { med_out[blockIdx.x] = sqrtf(__uint_as_float(prefix)); s->done = 1; s->fast = 0; s->n_amb = 0; }
+    for (int i = t; i < 4096; i += blockDim.x) s->hist[i] = 0;
 }
 
 // ---- fallback path (plain 3-level radix select; every kernel is a no-op when s->done) ---------------
@@ -1862,20 +1988,23 @@ static unsigned stat_blocks(int rows, int n_images) {
 
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident,
-                          hipStream_t s, const CapParams* cap, unsigned* partial, float* amb, unsigned long long* usable) {
+                          hipStream_t s, const CapParams* cap, unsigned* partial, float* amb, unsigned long long* usable, int compact) {
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
     const unsigned nb = stat_blocks(PH, n_images);
     const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    const unsigned fin_lds = (4096 + 256 + 16) * sizeof(unsigned) + 4 * sizeof(unsigned long long);
     const dim3 g3(nb, 3, n_images), gs(3 * n_images);
     unsigned nbc_used = 0;
-    hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
+    // compact: planes up to 2^24 bins -- 6 dependent launches instead of 16 (a single image is bound by their latency)
+    compact = compact && ((unsigned long long)PH * PW <= (1ull << 24));
+    if (!compact || force_fallback) hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
     if (!force_fallback) {
         // fast path: sample histogram -> bracket -> one verified pass
         int step = PH / 128; if (step < 1) step = 1; if (step > 16) step = 16;      // sample every step-th row
         unsigned nbs = (unsigned)((PH + step - 1) / step); if (nbs > nb) nbs = nb; if (nbs < 1) nbs = 1;
         hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
-        hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0);
+        hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
         // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
         // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
@@ -1891,28 +2020,40 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         else
             hipLaunchKernelGGL(k_collect_bracket<false>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                                img_stride, st, cand, cand_stride, 0ull, 0ull, 0, nullptr, nullptr);
-        hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
-        // candidates: ~13 % of a plane; 16 blocks per plane are plenty for a batch but left one 8192^2 image with 48 blocks in all (110 us)
-        unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
-        if (nbh < 16) nbh = 16;
-        if (nbh > 256) nbh = 256;
-        hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
-        hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
+        if (compact) {
+            hipLaunchKernelGGL(k_select_finish, gs, dim3(1024), fin_lds, s, st, cand, cand_stride, med_out, rank);
+        } else {
+            hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
+            // candidates: ~13 % of a plane; 16 blocks per plane are plenty for a batch but left one 8192^2 image with 48 blocks in all (110 us)
+            unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
+            if (nbh < 16) nbh = 16;
+            if (nbh > 256) nbh = 256;
+            hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
+            hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
+        }
     }
-    // fallback: plain three-level select; every block returns immediately when the fast path verified
-    hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1);
-    hipLaunchKernelGGL(k_select<1>, gs, dim3(256), sel_lds, s, st, med_out);
-    hipLaunchKernelGGL(k_collect, g3, dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M, img_stride, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
-    hipLaunchKernelGGL(k_hist_cand<false>, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    if (compact) {
+        // fallback: one block per plane, returns at once where the fast path verified
+        hipLaunchKernelGGL(k_median_fallback, gs, dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, force_fallback ? 1 : 0);
+    } else {
+        // fallback: plain three-level select; every block returns immediately when the fast path verified
+        hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1);
+        hipLaunchKernelGGL(k_select<1>, gs, dim3(256), sel_lds, s, st, med_out);
+        hipLaunchKernelGGL(k_collect, g3, dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M, img_stride, st, cand, cand_stride);
+        hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
+        hipLaunchKernelGGL(k_hist_cand<false>, dim3(16, 3, n_images), dim3(256), 512 * sizeof(unsigned), s, st, cand, cand_stride);
+        hipLaunchKernelGGL(k_select<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    }
     if (cap) {
         // capacity: settle the bracket pass's counts with the now known medians; images it could not settle (fallback median,
-        // overflowing park list, forced fallback: n_amb stays 0 but fast stays 0 too) are recounted by the plain kernel
+        // overflowing park list, forced fallback) are recounted -- inside the settle block (compact) or by the plain kernel
         unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;      // n_images words behind the partial counts
-        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)nbc_used, amb, usable, flag);
-        hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)nbc_used, amb, usable, flag,
+                           spec, *cap, compact ? 1 : 0);
+        if (!compact) {
+            hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipGetLastError();
 }
