@@ -1168,7 +1168,8 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
     {
         const bool compact = c->stats_compact && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
-        if (stage == MEDIANS) launches = compact ? (c->median_force_fallback ? 2 : 5) + (c->stats_fused ? 1 : 0)
+        const bool finish1 = compact && (unsigned long long)s.PH * s.PWi <= (1ull << 22);
+        if (stage == MEDIANS) launches = compact ? (c->median_force_fallback ? 2 : (finish1 ? 5 : 7)) + (c->stats_fused ? 1 : 0)
                                                  : (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);
     }
     if (stage == CAPACITY) launches = c->stats_fused ? 0 : 2;      // fused: counted inside the medians' full pass

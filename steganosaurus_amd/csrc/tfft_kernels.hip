@@ -1998,6 +1998,9 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     unsigned nbc_used = 0;
     // compact: planes up to 2^24 bins -- 6 dependent launches instead of 16 (a single image is bound by their latency)
     compact = compact && ((unsigned long long)PH * PW <= (1ull << 24));
+    // the merged finish kernel walks a plane's candidates (~13 % of its bins) with ONE block: fine up to 2048^2 (270 k candidates),
+    // too slow beyond (8 x 4K: 0.52 vs 0.43 ms for the whole statistics stage)
+    const bool finish1 = compact && ((unsigned long long)PH * PW <= (1ull << 22));
     if (!compact || force_fallback) hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
     if (!force_fallback) {
         // fast path: sample histogram -> bracket -> one verified pass
@@ -2010,7 +2013,9 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
         const int cus = fill_cus > 0 ? fill_cus : 256, resident = fill_resident > 0 ? fill_resident : 4;
         unsigned nbc = (unsigned)(((long long)cus * resident) / (3LL * n_images));
-        if (nbc > (unsigned)((PH + 3) / 4)) nbc = (unsigned)((PH + 3) / 4);
+        // at least 4 rows per wave: every block ends with up to ~770 global atomics (its level-2 histogram), and a single image
+        // spread over 426 one-row-per-wave blocks spent more time on those than on its rows (49 us for 50 MB)
+        if (nbc > (unsigned)((PH + 15) / 16)) nbc = (unsigned)((PH + 15) / 16);
         if (nbc > TFFT_STAT_MAX_BLOCKS) nbc = TFFT_STAT_MAX_BLOCKS;
         if (nbc < 1) nbc = 1;
         nbc_used = nbc;
@@ -2020,7 +2025,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         else
             hipLaunchKernelGGL(k_collect_bracket<false>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                                img_stride, st, cand, cand_stride, 0ull, 0ull, 0, nullptr, nullptr);
-        if (compact) {
+        if (finish1) {
             hipLaunchKernelGGL(k_select_finish, gs, dim3(1024), fin_lds, s, st, cand, cand_stride, med_out, rank);
         } else {
             hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
