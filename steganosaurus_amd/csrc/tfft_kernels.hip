@@ -367,6 +367,141 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const ui
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same fused kernel with LIVE rows only.  Of the N1 = 8 rows n1*N2 + n2 a workgroup covers, those below the image's
+// height are the first NL = ceil or floor(H / N2) (4 or 5 of 8 at 1920x1080 and 3840x2160); the others are padding.  The
+// kernel above keeps a wave (pair) and an LDS slab for every one of the 8: the waves of padded rows idle at the barriers and
+// their slabs hold zeros.  Here a workgroup has NL rows' worth of threads and slabs and nothing else, so a CU holds three
+// workgroups instead of two at 2048 columns (43-52 KB each) and two instead of one at 4096 columns with NL <= 4 (70 KB, pass
+// twiddles read from the L2-resident table instead of an LDS copy) -- the workgroups of a CU overlap each other's load,
+// transform and store phases, which is where these kernels get their bandwidth from.  The column phase loops over the M/2
+// column pairs with however many threads there are; rows >= NL enter the length-8 DFT as zeros.
+//   launched once per value of NL: grid (3 * n2_cnt, n_images), block (T, NL), rows n2 in [n2_lo, n2_lo + n2_cnt)
+// ---------------------------------------------------------------------------
+template <int LOGM, int NL>
+__global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_rowcol_fwd_live(const uint8_t* __restrict__ rgb, float2* __restrict__ out,
+                             const float2* __restrict__ tw, const float2* __restrict__ tw_h, RowParams P, int n2_lo, int n2_cnt) {
+    constexpr int M = 1 << LOGM, E = 16, T = M / E, N1 = 8, NTHR = T * NL;
+    constexpr bool LTW = (LOGM <= 10);                  // pass twiddles: LDS copy (2048 columns) or the global table (4096 columns)
+    constexpr int NPAIR = ((M / 2) + NTHR - 1) / NTHR;  // column pairs per thread
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
+    const int t = threadIdx.x, n1 = threadIdx.y, tid = n1 * T + t;
+    const int N2 = P.PH >> 3;
+    int n2, plane;
+    xcd_plane_order(n2_cnt, n2, plane);
+    n2 += n2_lo;
+    const int img = blockIdx.y;
+    const int y = n1 * N2 + n2;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+    const bool live = y < P.H;          // always true except for images shorter than N2 rows (NL = 1 covers their padded groups)
+    float2* ltw = lds + (size_t)NL * lay.pitch;
+    float2* lwc = ltw + (LTW ? M : 0);
+
+    // ---- prologue: every global load before the first dependent LDS store (see k_rowcol_fwd)
+    constexpr int NT = LTW ? (M + NTHR - 1) / NTHR : 1;
+    float2 tv[NT];
+    if (LTW) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) tv[i] = tw[2 * imin(tid + i * NTHR, M - 1)];
+    }
+    float2 cv = make_float2(0.f, 0.f);
+    if (tid < N1) cv = tw_h[(n2 * tid) & (P.PH - 1)];
+    float2 wsx[NPAIR];
+#pragma unroll
+    for (int i = 0; i < NPAIR; i++) wsx[i] = tw[imin(tid + i * NTHR, M / 2)];      // split twiddles exp(+2 pi i x/PW) of this thread's pairs
+    const float2 wsh = tw[M / 2];
+    const uint8_t* src = rgb + ((size_t)img * P.H + (live ? y : 0)) * (size_t)(P.W * 3);
+    const bool fastp = live && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    constexpr int GMAX = (2 * M / 4) / T;
+    const int ng = P.W >> 2;
+    uint32_t ra[GMAX], rb[GMAX], rc[GMAX];
+    if (fastp) {
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src);
+#pragma unroll
+        for (int i = 0; i < GMAX; i++) {
+            const int g = imin(t + i * T, ng - 1);
+            ra[i] = srcw[3 * g]; rb[i] = srcw[3 * g + 1]; rc[i] = srcw[3 * g + 2];
+        }
+    }
+    if (LTW) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) if (tid + i * NTHR < M) ltw[tid + i * NTHR] = tv[i];
+    }
+    if (tid < N1) lwc[tid] = cv;
+    if (fastp) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+#pragma unroll
+        for (int i = 0; i < GMAX; i++) {
+            const int g = t + i * T;
+            if (g < ng) {
+                float v0, v1, v2, v3;
+                plane_samples4(ra[i], rb[i], rc[i], plane, P.bias, v0, v1, v2, v3);
+                lds[lay.idx(2 * g, n1)] = make_float2(s0 * v0, s1 * v1);
+                lds[lay.idx(2 * g + 1, n1)] = make_float2(s0 * v2, s1 * v3);
+            }
+        }
+        for (int m = (P.W >> 1) + t; m < M; m += T) lds[lay.idx(m, n1)] = make_float2(0.f, 0.f);
+    } else if (live) {
+        for (int n = t; n < 2 * M; n += T) {
+            float v = 0.0f;
+            if (n < P.W) { v = (float)src[3 * n + plane] - P.bias; if (P.center && ((n + y) & 1)) v = -v; }
+            ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
+        }
+    }
+    __syncthreads();
+    {
+        float2 u[E];
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+        }
+        Sync::sync();
+        if (LTW) fft_block_lazy<M, E, +1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
+        else fft_block_lazy<M, E, +1, Sync>(u, lds, lay, t, n1, tw, 2, live);
+#pragma unroll
+        for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+
+    // ---- real-FFT split + length-8 DFT across the rows per column pair (x, M-x); rows >= NL are zeros
+    float2 wc[N1];
+#pragma unroll
+    for (int k1 = 0; k1 < N1; k1++) wc[k1] = lwc[k1];
+    float2* dst = out + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
+#pragma unroll
+    for (int i = 0; i < NPAIR; i++) {
+        const int px = tid + i * NTHR;
+        if (px >= M / 2) break;
+        const int xa = px, xb = (px == 0) ? M / 2 : M - px;
+        float2 va[N1], vb[N1];
+#pragma unroll
+        for (int r = 0; r < N1; r++) {
+            if (r < NL) {
+                const float2 zk = lds[lay.idx(xa, r)], zm = lds[lay.idx((M - xa) & (M - 1), r)];
+                rsplit_fwd(zk, zm, wsx[i], va[r], vb[r]);
+                if (px == 0) {
+                    va[r] = make_float2(va[r].x, vb[r].x);                                     // X[0] and X[M] (w = 1), both real, packed
+                    const float2 zh = lds[lay.idx(M / 2, r)];                                  // column M/2 pairs with itself
+                    const float2 ah = make_float2(zh.x, 0.0f), dh = make_float2(0.0f, 2.0f * zh.y);
+                    const float2 odh = make_float2(0.5f * dh.y, -0.5f * dh.x);
+                    vb[r] = cadd(ah, cmul(wsh, odh));
+                }
+            } else {
+                va[r] = make_float2(0.f, 0.f); vb[r] = make_float2(0.f, 0.f);
+            }
+        }
+        DftReg<N1, +1, 0, N1>::run(va);
+        DftReg<N1, +1, 0, N1>::run(vb);
+#pragma unroll
+        for (int k1 = 0; k1 < N1; k1++) {
+            dst[(size_t)k1 * N2 * M + xa] = cmul(va[bitrev(k1, 3)], wc[k1]);
+            dst[(size_t)k1 * N2 * M + xb] = cmul(vb[bitrev(k1, 3)], wc[k1]);
+        }
+    }
+}
+
 // clamp(round(v), 0, 255) with C round() semantics (half away from zero, S:389) for the values that
 // survive the clamp: negatives go to 0 either way, so only v >= 0 needs exact half-up rounding
 // (v - trunc(v) is exact in fp32, unlike v + 0.5f).
@@ -469,6 +604,102 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
         if (!live) return;
     }
 
+    // ---- quantise and store this plane's bytes of row y
+    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
+    if ((P.W & 1) == 0) {
+        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
+        for (int m = t; m < (P.W >> 1); m += T) {
+            const float2 v = lds[lay.idx(m, n1)];
+            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
+            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
+        }
+    } else {
+        for (int n = t; n < P.W; n += T) {
+            float v = ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)];
+            if (P.center && ((n + y) & 1)) v = -v;
+            dst[3 * n] = (uint8_t)quantise_u8(v + P.bias);
+        }
+    }
+}
+
+// The fused inverse with LIVE rows only (see k_rowcol_fwd_live): NL rows' worth of threads and slabs, the column phase loops
+// over the column pairs, rows >= NL of the length-8 inverse DFT are never written anywhere.
+//   launched once per value of NL: grid (3 * n2_cnt, n_images), block (T, NL)
+template <int LOGM, int NL>
+__global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_colrow_inv_live(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
+                             const float2* __restrict__ tw, RowParams P, int n2_lo, int n2_cnt) {
+    constexpr int M = 1 << LOGM, E = 16, T = M / E, N1 = 8, NTHR = T * NL;
+    constexpr bool LTW = (LOGM <= 10);
+    constexpr int NPAIR = ((M / 2) + NTHR - 1) / NTHR;
+    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
+    const int t = threadIdx.x, n1 = threadIdx.y, tid = n1 * T + t;
+    const int N2 = P.PH >> 3;
+    int n2, plane;
+    xcd_plane_order(n2_cnt, n2, plane);
+    n2 += n2_lo;
+    const int img = blockIdx.y;
+    const int y = n1 * N2 + n2;
+    float2* lds = reinterpret_cast<float2*>(tfft_smem);
+    float* ldsf = reinterpret_cast<float*>(tfft_smem);
+    LayRows lay{LayRows::padded(M)};
+    float2* ltw = lds + (size_t)NL * lay.pitch;
+    constexpr int NT = LTW ? (M + NTHR - 1) / NTHR : 1;
+    float2 tv[NT];
+    if (LTW) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) tv[i] = tw[2 * imin(tid + i * NTHR, M - 1)];
+    }
+    const float2 wsh = tw[M / 2];
+    const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
+#pragma unroll
+    for (int i = 0; i < NPAIR; i++) {
+        const int px = tid + i * NTHR;
+        if (px >= M / 2) break;
+        const int xa = px, xb = (px == 0) ? M / 2 : M - px;
+        const float2 wsx = tw[px];
+        float2 va[N1], vb[N1];
+#pragma unroll
+        for (int k1 = 0; k1 < N1; k1++) { va[k1] = src[(size_t)k1 * N2 * M + xa]; vb[k1] = src[(size_t)k1 * N2 * M + xb]; }
+        DftReg<N1, -1, 0, N1>::run(va);
+        DftReg<N1, -1, 0, N1>::run(vb);
+#pragma unroll
+        for (int r = 0; r < NL; r++) {
+            if (r * N2 + n2 >= P.H) continue;                 // workgroup uniform (images shorter than N2 rows)
+            const float2 xk = va[bitrev(r, 3)], xm = vb[bitrev(r, 3)];
+            if (px == 0) {
+                lds[lay.idx(0, r)] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));      // X[0], X[M] packed in bin 0
+                const float2 od = cmul(make_float2(0.0f, xm.y), cconj(wsh));                       // column M/2 pairs with itself
+                lds[lay.idx(M / 2, r)] = make_float2(xm.x - od.y, 0.0f + od.x);
+            } else {
+                float2 za, zb;
+                rsplit_inv(xk, xm, wsx, za, zb);
+                lds[lay.idx(xa, r)] = za;
+                lds[lay.idx(xb, r)] = zb;
+            }
+        }
+    }
+    if (LTW) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) if (tid + i * NTHR < M) ltw[tid + i * NTHR] = tv[i];
+    }
+    __syncthreads();
+    const bool live = y < P.H;
+    {
+        float2 u[E];
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
+        }
+        Sync::sync();
+        if (LTW) fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
+        else fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, tw, 2, live);
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
+        }
+        Sync::sync();
+        if (!live) return;
+    }
     // ---- quantise and store this plane's bytes of row y
     uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
     if ((P.W & 1) == 0) {
@@ -1884,6 +2115,61 @@ hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw
     if (P.PW == 2048) return launch_colrow_inv_t<10>(in, rgb, tw_pw, P, n_images, s);
     if (P.PW == 4096) return launch_colrow_inv_t<11>(in, rgb, tw_pw, P, n_images, s);
     return hipErrorInvalidValue;
+}
+// live-rows-only variants: one launch per distinct number of live rows NL among the groups n2 (at most two values)
+template <int LOGM, int NL, bool FWD>
+static hipError_t launch_fused_live_t(const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
+                                      int n2_lo, int n2_cnt, hipStream_t s) {
+    constexpr int M = 1 << LOGM;
+    const size_t lds = ((size_t)NL * LayRows::padded(M) + (LOGM <= 10 ? M : 0) + (FWD ? 8 : 0)) * sizeof(float2);
+    if (FWD) {
+        auto k = k_rowcol_fwd_live<LOGM, NL>;
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(n2_cnt * 3, n_images), dim3(M / 16, NL), lds, s, (const uint8_t*)in, (float2*)out, tw_pw, tw_ph, P, n2_lo, n2_cnt);
+    } else {
+        auto k = k_colrow_inv_live<LOGM, NL>;
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(n2_cnt * 3, n_images), dim3(M / 16, NL), lds, s, (const float2*)in, (uint8_t*)out, tw_pw, P, n2_lo, n2_cnt);
+    }
+    return hipGetLastError();
+}
+template <int LOGM, bool FWD>
+static hipError_t launch_fused_live_nl(int nl, const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
+                                       int n2_lo, int n2_cnt, hipStream_t s) {
+    // PH = next_pow2(H) < 2H and N2 = PH/8, so 4 < H/N2 <= 8: a group has 4 .. 8 live rows
+    switch (nl) {
+        case 4: return launch_fused_live_t<LOGM, 4, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 5: return launch_fused_live_t<LOGM, 5, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 6: return launch_fused_live_t<LOGM, 6, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 7: return launch_fused_live_t<LOGM, 7, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        default: return launch_fused_live_t<LOGM, 8, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+    }
+}
+// groups n2 < H mod N2 have ceil(H/N2) live rows, the others floor(H/N2) (at least one slab: a group without live rows still has to
+// write its zeros on the way in, and writes nothing on the way out)
+template <bool FWD>
+static hipError_t launch_fused_live(const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s) {
+    const int N2 = P.PH >> 3, hi = P.H / N2, rem = P.H % N2;
+    hipError_t e = hipSuccess;
+    for (int part = 0; part < 2 && e == hipSuccess; part++) {
+        const int lo = part ? rem : 0, cnt = part ? N2 - rem : rem;
+        int nl = part ? hi : hi + 1;
+        if (cnt == 0) continue;
+        if (nl < 4) nl = 4;
+        if (nl > 8) nl = 8;
+        if (P.PW == 2048) e = launch_fused_live_nl<10, FWD>(nl, in, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
+        else if (P.PW == 4096) e = launch_fused_live_nl<11, FWD>(nl, in, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
+        else e = hipErrorInvalidValue;
+    }
+    return e;
+}
+hipError_t launch_rowcol_fwd_live(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s) {
+    return launch_fused_live<true>(rgb, out, tw_pw, tw_ph, P, n_images, s);
+}
+hipError_t launch_colrow_inv_live(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
+    return launch_fused_live<false>(in, rgb, tw_pw, nullptr, P, n_images, s);
 }
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s) {

@@ -67,6 +67,23 @@ def test_columns_of_512_with_lds_twiddles(emu, orc):
         del os.environ["TFFT_COLS_LOG_N1"]
 
 
+def test_fused_live_row_counts(emu, orc):
+    """The live-rows-only fused kernels at both widths for every shape of a group: H below N2 (one slab, groups without any live row
+    write zeros), H = a multiple of N2 (one launch), NL = 8 (nothing padded), and two different counts in one image."""
+    os.environ["TFFT_FUSE_WIDE"] = "2"
+    try:
+        PC.check_forward_against_oracle(emu, orc, [(1100, 10), (1200, 128), (1030, 96), (2049, 100), (2100, 136)], centers=(0, 1))
+        PC.check_identity_roundtrip(emu, [(1100, 10), (2047, 128), (1500, 200), (2100, 256), (2200, 24)])
+    finally:
+        del os.environ["TFFT_FUSE_WIDE"]
+    os.environ["TFFT_FUSE_LIVE"] = "0"          # the all-rows kernels stay correct (A/B path)
+    try:
+        PC.check_forward_against_oracle(emu, orc, [(1500, 130)], centers=(1,))
+        PC.check_identity_roundtrip(emu, [(1500, 130)])
+    finally:
+        del os.environ["TFFT_FUSE_LIVE"]
+
+
 def test_fused_rows_plus_column_step_4096_wide(emu, orc):
     # PW = 4096 and 128 <= PH <= 4096: the same fused kernels with two waves per row (workgroup barriers inside the row transform,
     # which the waves of padded rows sit out): live rows only in the first rows of a workgroup, odd width, centring
