@@ -98,7 +98,7 @@ struct tfft_ctx {
     int stats_compact = 1;                // TFFT_STATS_COMPACT=0: the 16-launch statistics pipeline also for small planes (A/B)
     int fuse = 1;
     int fuse_wide = 1;
-    int fuse_live = 1;                    // TFFT_FUSE_LIVE=0: the fused kernels with a wave (pair) and a slab for all 8 rows of a group (A/B)
+    int fuse_live = 1;                    // TFFT_FUSE_LIVE=0: the fused forward kernel with a wave (pair) and a slab for all 8 rows of a group (A/B)
 
     uint8_t* img(int i) const { return img_pool + (size_t)i * img_stride_b; }
     float2* spec(int i) const { return spec_pool + (size_t)i * slot_stride; }
@@ -196,7 +196,8 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     switch (stage) {
         case ROWS_FWD: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->dc_bias};
-            if (pl.fused_fwd && c->fuse_live) HIPCHK(c, launch_rowcol_fwd_live(rgb_in, tmp, tw_w, tw_h, rp, n, st));   // rows + column step A, live rows only
+            // rows + column step A; when some rows of the groups are padding, by the live-rows-only kernel (a full-height image has none)
+            if (pl.fused_fwd && c->fuse_live && s.H < s.PH) HIPCHK(c, launch_rowcol_fwd_live(rgb_in, tmp, tw_w, tw_h, rp, n, st));
             else if (pl.fused_fwd) HIPCHK(c, launch_rowcol_fwd(rgb_in, tmp, tw_w, tw_h, rp, n, st));
             else HIPCHK(c, launch_rows_fwd(rgb_in, tmp, tw_w, rp, n, st));
             return TFFT_OK;
@@ -254,8 +255,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             return TFFT_OK;
         case ROWS_INV: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias};
-            if (pl.fused_fwd && c->fuse_live) HIPCHK(c, launch_colrow_inv_live(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows, live rows only
-            else if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));
+            if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
             else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
         }

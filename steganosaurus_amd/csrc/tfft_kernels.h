@@ -114,9 +114,8 @@ hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw,
 hipError_t launch_rowcol_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P,
                              int n_images, hipStream_t s);
 hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s);
-// the same two stages with threads and LDS for the LIVE rows of every group only (one launch per distinct live-row count)
+// the forward stage with threads and LDS for the LIVE rows of every group only (one launch per distinct live-row count)
 hipError_t launch_rowcol_fwd_live(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s);
-hipError_t launch_colrow_inv_live(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s);
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s);
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,

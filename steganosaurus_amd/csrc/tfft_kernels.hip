@@ -622,102 +622,6 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     }
 }
 
-// The fused inverse with LIVE rows only (see k_rowcol_fwd_live): NL rows' worth of threads and slabs, the column phase loops
-// over the column pairs, rows >= NL of the length-8 inverse DFT are never written anywhere.
-//   launched once per value of NL: grid (3 * n2_cnt, n_images), block (T, NL)
-template <int LOGM, int NL>
-__global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_colrow_inv_live(const float2* __restrict__ in, uint8_t* __restrict__ rgb,
-                             const float2* __restrict__ tw, RowParams P, int n2_lo, int n2_cnt) {
-    constexpr int M = 1 << LOGM, E = 16, T = M / E, N1 = 8, NTHR = T * NL;
-    constexpr bool LTW = (LOGM <= 10);
-    constexpr int NPAIR = ((M / 2) + NTHR - 1) / NTHR;
-    using Sync = typename std::conditional<T == 64, WaveSync, BlockSync>::type;
-    const int t = threadIdx.x, n1 = threadIdx.y, tid = n1 * T + t;
-    const int N2 = P.PH >> 3;
-    int n2, plane;
-    xcd_plane_order(n2_cnt, n2, plane);
-    n2 += n2_lo;
-    const int img = blockIdx.y;
-    const int y = n1 * N2 + n2;
-    float2* lds = reinterpret_cast<float2*>(tfft_smem);
-    float* ldsf = reinterpret_cast<float*>(tfft_smem);
-    LayRows lay{LayRows::padded(M)};
-    float2* ltw = lds + (size_t)NL * lay.pitch;
-    constexpr int NT = LTW ? (M + NTHR - 1) / NTHR : 1;
-    float2 tv[NT];
-    if (LTW) {
-#pragma unroll
-        for (int i = 0; i < NT; i++) tv[i] = tw[2 * imin(tid + i * NTHR, M - 1)];
-    }
-    const float2 wsh = tw[M / 2];
-    const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
-#pragma unroll
-    for (int i = 0; i < NPAIR; i++) {
-        const int px = tid + i * NTHR;
-        if (px >= M / 2) break;
-        const int xa = px, xb = (px == 0) ? M / 2 : M - px;
-        const float2 wsx = tw[px];
-        float2 va[N1], vb[N1];
-#pragma unroll
-        for (int k1 = 0; k1 < N1; k1++) { va[k1] = src[(size_t)k1 * N2 * M + xa]; vb[k1] = src[(size_t)k1 * N2 * M + xb]; }
-        DftReg<N1, -1, 0, N1>::run(va);
-        DftReg<N1, -1, 0, N1>::run(vb);
-#pragma unroll
-        for (int r = 0; r < NL; r++) {
-            if (r * N2 + n2 >= P.H) continue;                 // workgroup uniform (images shorter than N2 rows)
-            const float2 xk = va[bitrev(r, 3)], xm = vb[bitrev(r, 3)];
-            if (px == 0) {
-                lds[lay.idx(0, r)] = make_float2(0.5f * (xk.x + xk.y), 0.5f * (xk.x - xk.y));      // X[0], X[M] packed in bin 0
-                const float2 od = cmul(make_float2(0.0f, xm.y), cconj(wsh));                       // column M/2 pairs with itself
-                lds[lay.idx(M / 2, r)] = make_float2(xm.x - od.y, 0.0f + od.x);
-            } else {
-                float2 za, zb;
-                rsplit_inv(xk, xm, wsx, za, zb);
-                lds[lay.idx(xa, r)] = za;
-                lds[lay.idx(xb, r)] = zb;
-            }
-        }
-    }
-    if (LTW) {
-#pragma unroll
-        for (int i = 0; i < NT; i++) if (tid + i * NTHR < M) ltw[tid + i * NTHR] = tv[i];
-    }
-    __syncthreads();
-    const bool live = y < P.H;
-    {
-        float2 u[E];
-        if (live) {
-#pragma unroll
-            for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, n1)];
-        }
-        Sync::sync();
-        if (LTW) fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, ltw, 1, live);
-        else fft_block_lazy<M, E, -1, Sync>(u, lds, lay, t, n1, tw, 2, live);
-        if (live) {
-#pragma unroll
-            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = cscale(u[m], P.scale);
-        }
-        Sync::sync();
-        if (!live) return;
-    }
-    // ---- quantise and store this plane's bytes of row y
-    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
-    if ((P.W & 1) == 0) {
-        const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
-        for (int m = t; m < (P.W >> 1); m += T) {
-            const float2 v = lds[lay.idx(m, n1)];
-            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
-            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
-        }
-    } else {
-        for (int n = t; n < P.W; n += T) {
-            float v = ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)];
-            if (P.center && ((n + y) & 1)) v = -v;
-            dst[3 * n] = (uint8_t)quantise_u8(v + P.bias);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // rows, inverse: M half-spectrum bins -> real row of length PW (only x < W is
 // produced) -> scale -> (centring) -> round half away, clamp, interleave u8.
@@ -2116,41 +2020,34 @@ hipError_t launch_colrow_inv(const float2* in, uint8_t* rgb, const float2* tw_pw
     if (P.PW == 4096) return launch_colrow_inv_t<11>(in, rgb, tw_pw, P, n_images, s);
     return hipErrorInvalidValue;
 }
-// live-rows-only variants: one launch per distinct number of live rows NL among the groups n2 (at most two values)
-template <int LOGM, int NL, bool FWD>
-static hipError_t launch_fused_live_t(const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
-                                      int n2_lo, int n2_cnt, hipStream_t s) {
+// live-rows-only forward: one launch per distinct number of live rows NL among the groups n2 (at most two values).  (The inverse
+// was tried the same way and is no faster -- 0.623 vs 0.613 ms per 8 x 4K launch, 0.416 vs 0.407 per 32 x 1080p: its column phase
+// comes first and is all loads, for which the waves of the padded rows are useful help before they exit.)
+template <int LOGM, int NL>
+static hipError_t launch_fwd_live_t(const uint8_t* in, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
+                                    int n2_lo, int n2_cnt, hipStream_t s) {
     constexpr int M = 1 << LOGM;
-    const size_t lds = ((size_t)NL * LayRows::padded(M) + (LOGM <= 10 ? M : 0) + (FWD ? 8 : 0)) * sizeof(float2);
-    if (FWD) {
-        auto k = k_rowcol_fwd_live<LOGM, NL>;
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(n2_cnt * 3, n_images), dim3(M / 16, NL), lds, s, (const uint8_t*)in, (float2*)out, tw_pw, tw_ph, P, n2_lo, n2_cnt);
-    } else {
-        auto k = k_colrow_inv_live<LOGM, NL>;
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(n2_cnt * 3, n_images), dim3(M / 16, NL), lds, s, (const float2*)in, (uint8_t*)out, tw_pw, P, n2_lo, n2_cnt);
-    }
+    const size_t lds = ((size_t)NL * LayRows::padded(M) + (LOGM <= 10 ? M : 0) + 8) * sizeof(float2);
+    auto k = k_rowcol_fwd_live<LOGM, NL>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n2_cnt * 3, n_images), dim3(M / 16, NL), lds, s, in, out, tw_pw, tw_ph, P, n2_lo, n2_cnt);
     return hipGetLastError();
 }
-template <int LOGM, bool FWD>
-static hipError_t launch_fused_live_nl(int nl, const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
-                                       int n2_lo, int n2_cnt, hipStream_t s) {
+template <int LOGM>
+static hipError_t launch_fwd_live_nl(int nl, const uint8_t* in, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images,
+                                     int n2_lo, int n2_cnt, hipStream_t s) {
     // PH = next_pow2(H) < 2H and N2 = PH/8, so 4 < H/N2 <= 8: a group has 4 .. 8 live rows
     switch (nl) {
-        case 4: return launch_fused_live_t<LOGM, 4, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
-        case 5: return launch_fused_live_t<LOGM, 5, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
-        case 6: return launch_fused_live_t<LOGM, 6, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
-        case 7: return launch_fused_live_t<LOGM, 7, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
-        default: return launch_fused_live_t<LOGM, 8, FWD>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 4: return launch_fwd_live_t<LOGM, 4>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 5: return launch_fwd_live_t<LOGM, 5>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 6: return launch_fwd_live_t<LOGM, 6>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        case 7: return launch_fwd_live_t<LOGM, 7>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
+        default: return launch_fwd_live_t<LOGM, 8>(in, out, tw_pw, tw_ph, P, n_images, n2_lo, n2_cnt, s);
     }
 }
-// groups n2 < H mod N2 have ceil(H/N2) live rows, the others floor(H/N2) (at least one slab: a group without live rows still has to
-// write its zeros on the way in, and writes nothing on the way out)
-template <bool FWD>
-static hipError_t launch_fused_live(const void* in, void* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s) {
+// groups n2 < H mod N2 have ceil(H/N2) live rows, the others floor(H/N2)
+hipError_t launch_rowcol_fwd_live(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s) {
     const int N2 = P.PH >> 3, hi = P.H / N2, rem = P.H % N2;
     hipError_t e = hipSuccess;
     for (int part = 0; part < 2 && e == hipSuccess; part++) {
@@ -2159,17 +2056,11 @@ static hipError_t launch_fused_live(const void* in, void* out, const float2* tw_
         if (cnt == 0) continue;
         if (nl < 4) nl = 4;
         if (nl > 8) nl = 8;
-        if (P.PW == 2048) e = launch_fused_live_nl<10, FWD>(nl, in, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
-        else if (P.PW == 4096) e = launch_fused_live_nl<11, FWD>(nl, in, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
+        if (P.PW == 2048) e = launch_fwd_live_nl<10>(nl, rgb, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
+        else if (P.PW == 4096) e = launch_fwd_live_nl<11>(nl, rgb, out, tw_pw, tw_ph, P, n_images, lo, cnt, s);
         else e = hipErrorInvalidValue;
     }
     return e;
-}
-hipError_t launch_rowcol_fwd_live(const uint8_t* rgb, float2* out, const float2* tw_pw, const float2* tw_ph, const RowParams& P, int n_images, hipStream_t s) {
-    return launch_fused_live<true>(rgb, out, tw_pw, tw_ph, P, n_images, s);
-}
-hipError_t launch_colrow_inv_live(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images, hipStream_t s) {
-    return launch_fused_live<false>(in, rgb, tw_pw, nullptr, P, n_images, s);
 }
 hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s) {
