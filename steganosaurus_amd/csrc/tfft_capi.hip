@@ -93,7 +93,9 @@ struct tfft_ctx {
     struct GraphEntry { hipGraphExec_t exec = nullptr; int state = 0; };
     std::map<std::vector<uint64_t>, GraphEntry> graphs;
 #endif
-    int graph_max_images = 4;             // TFFT_GRAPHS=0 disables; larger calls are bandwidth bound and gain nothing
+    int graph_max_images = 0;             // TFFT_GRAPHS=n: replay calls of up to n images.  Off by default: measured 5 % SLOWER than plain
+                                          // launches (0.283 vs 0.267 ms per 1080p round trip) -- a single image is bound by the GPU-side
+                                          // latency of its dependent kernels, which a graph does not shorten
     int stats_fused = 1;                  // TFFT_STATS_FUSED=0: capacity as its own pass after the medians (A/B)
     int stats_compact = 1;                // TFFT_STATS_COMPACT=0: the 16-launch statistics pipeline also for small planes (A/B)
     int fuse = 1;
