@@ -1172,6 +1172,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     int launches = 1;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
+    if (stage == ROWS_FWD && pl.fused_fwd && c->fuse_live && s.H < s.PH && (s.H % (s.PH >> 3)) != 0) launches = 2;      // one per live-row count
     {
         const bool compact = c->stats_compact && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
         const bool finish1 = compact && (unsigned long long)s.PH * s.PWi <= (1ull << 22);

@@ -26,7 +26,17 @@ def match(pattern):
     return (kib(best), best) if best else (None, None)
 
 
+def match_sum(pattern):
+    """a stage that is several launches of sibling kernels (the live-rows fused forward: one per live-row count)"""
+    names = [n for n in S if re.match(pattern, n) and kib(n) is not None]
+    return (sum(kib(n) for n in names), " + ".join(sorted(names))) if names else (None, None)
+
+
 stages, kernels = {}, {}
+b, name = match_sum(r"k_rowcol_fwd_live<")
+if b is not None:
+    stages["rows_fwd"] = int(b * 1024)
+    kernels["rows_fwd"] = name
 for stage, pat in {
     "rows_fwd": r"k_rowcol_fwd<|k_rows_fwd<",
     "rows_inv": r"k_colrow_inv<|k_rows_inv<",
@@ -37,11 +47,13 @@ for stage, pat in {
     "cols_inv_b": r"k_fft_cols<\d+, -1, 0, false, false>",               # last inverse column step (three-pass plans)
     "embed": r"k_embed$", "read": r"k_read$", "capacity": r"k_capacity<",
 }.items():
+    if stage in stages:
+        continue
     b, name = match(pat)
     if b is not None:
         stages[stage] = int(b * 1024)
         kernels[stage] = name
-med = [kib(k) for k in S if k.startswith("k_collect_bracket")] + [2 * (kib("k_hist_spec") or 0), kib("k_hist_cand<true>") or 0]
+med = [kib(k) for k in S if k.startswith("k_collect_bracket")] + [kib("k_hist_spec") or 0, kib("k_hist_cand<true>") or 0]
 if med and med[0] is not None:
     stages["medians"] = int(sum(med) * 1024)
 T = json.load(open(out)) if os.path.exists(out) else {}
