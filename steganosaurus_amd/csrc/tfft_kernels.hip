@@ -41,11 +41,18 @@
 // column kernels of length >= 2^this read their inter-pass twiddles from an LDS copy of the table instead of holding them in
 // registers.  Needed at 512 (no spills); measured at 256 as well (round 2 A/B, one box): final forward step 0.614 vs 0.640 ms
 // per 32x1080p launch, nothing lost elsewhere; shorter lengths: no difference
+// elements per thread of the one-plane row kernels for rows of 2^TFFT_ROWS_E8_LOG complex samples and more (8: twice the threads per
+// row, one more LDS exchange, about half the registers); 99 = never
+#ifndef TFFT_ROWS_E8_LOG
+#define TFFT_ROWS_E8_LOG 99
+#endif
 #ifndef TFFT_COLS_LDS_TW_LOG
 #define TFFT_COLS_LDS_TW_LOG 8
 #endif
 
 namespace tfft {
+
+constexpr int rows_elems(int logm) { return logm >= TFFT_ROWS_E8_LOG ? 8 : elems_for(1 << logm); }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tfft_smem[];
 
@@ -90,10 +97,10 @@ __device__ __forceinline__ void plane_samples4(uint32_t a, uint32_t b, uint32_t 
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)   T = M/E
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
+__global__ void __launch_bounds__((1 << LOGM) / rows_elems(LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
 k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const float2* __restrict__ tw,
                            RowParams P) {
-    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    constexpr int M = 1 << LOGM, E = rows_elems(LOGM), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
     int y = blockIdx.x, plane0 = blockIdx.y * PPB;
     if (PPB == 1) xcd_plane_order(P.H, y, plane0);      // grid.x = 3*H: the three planes of a row on one XCD, back to back
@@ -630,10 +637,10 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
 //   grid  (H, 3/PPB, n_images)   block (T, PPB)
 // ---------------------------------------------------------------------------
 template <int LOGM, int PPB>
-__global__ void __launch_bounds__((1 << LOGM) / elems_for(1 << LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
+__global__ void __launch_bounds__((1 << LOGM) / rows_elems(LOGM) * PPB) TFFT_WAVES_PER_EU(LOGM >= TFFT_ROWS_LAZY_LOG ? 4 : 1)
 k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float2* __restrict__ tw,
                            RowParams P) {
-    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    constexpr int M = 1 << LOGM, E = rows_elems(LOGM), T = M / E;
     const int t = threadIdx.x, pb = threadIdx.y;
     int y = blockIdx.x, plane0 = blockIdx.y * PPB;
     if (PPB == 1) xcd_plane_order(P.H, y, plane0);      // grid.x = 3*H: the three planes of a row on one XCD, back to back
@@ -1959,7 +1966,7 @@ constexpr int rows_ppb(int logm) { return logm <= 10 ? 3 : 1; }   // wide rows: 
 template <int LOGM, int PPB, bool FWD>
 static hipError_t launch_rows_t(const void* in, void* out, const float2* tw, const RowParams& P, int n_images,
                                 hipStream_t s) {
-    constexpr int M = 1 << LOGM, E = elems_for(M), T = M / E;
+    constexpr int M = 1 << LOGM, E = rows_elems(LOGM), T = M / E;
     const size_t lds = (size_t)PPB * LayRows::padded(M) * sizeof(float2);
     dim3 grid(PPB == 1 ? P.H * 3 : P.H, PPB == 1 ? 1 : 3 / PPB, n_images), block(T, PPB, 1);
     if (FWD) {
