@@ -442,27 +442,30 @@ def main():
 
 
 def pcie_leg(wl, torch):
-    """side figure, never `value`: the same work when the caller hands over HOST buffers (pinned): tfft_embed_batch /
-    tfft_extract_batch overlap the PCIe copies with the kernels on three streams (bit-level interface: one byte per bit)"""
+    """side figure, never `value`: the same step when the caller hands over HOST buffers (pinned): tfft_embed_stream_batch /
+    tfft_extract_stream_batch overlap the PCIe copies with the kernels on three streams; covers and stego images cross the bus
+    as u8, the streams as packed bytes (38 + payload bytes per image in, header + payload + a status word out)"""
     import ctypes as C
-    n_img, W, H, n_bits = wl.n_img, wl.W, wl.H, wl.n_bits
-    bits = np.stack([rep_stream(wl.header[i], wl.payload[i]) for i in range(n_img)])
-    bins = np.ascontiguousarray(wl.bins_walk[:n_bits])
+    n_img, W, H = wl.n_img, wl.W, wl.H
+    bins = np.ascontiguousarray(wl.bins_walk)
     ctx = wl.S.Context(W, H, slots=wl.slots, device=wl.dev.index or 0)
     h_img = torch.from_numpy(wl.covers).pin_memory()
-    h_bits = torch.from_numpy(bits).pin_memory()
+    h_hdr = torch.from_numpy(wl.header).pin_memory()
+    h_pay = torch.from_numpy(wl.payload).pin_memory()
     h_stego = torch.empty(h_img.shape, dtype=torch.uint8).pin_memory()
-    h_raw = torch.empty(h_bits.shape, dtype=torch.uint8).pin_memory()
+    h_hdr2 = torch.zeros(h_hdr.shape, dtype=torch.uint8).pin_memory()
+    h_pay2 = torch.zeros(h_pay.shape, dtype=torch.uint8).pin_memory()
+    h_st = torch.zeros(n_img, dtype=torch.int32).pin_memory()
     h_us = torch.zeros(n_img, dtype=torch.int64).pin_memory()
     lib, hnd = ctx.lib, ctx.h
 
     def host_step():
-        rc = lib.tfft_embed_batch(hnd, n_img, C.c_void_p(h_img.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
-                                  C.c_void_p(h_bits.data_ptr()), n_bits, 0.5, 0.05, 0.45, 0.01,
-                                  C.c_void_p(h_us.data_ptr()) if wl.stats else None, C.c_void_p(h_stego.data_ptr()))
+        rc = lib.tfft_embed_stream_batch(hnd, n_img, C.c_void_p(h_img.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data), len(bins),
+                                         C.c_void_p(h_hdr.data_ptr()), C.c_void_p(h_pay.data_ptr()), wl.plen, 0.5, 0.05, 0.45, 0.01,
+                                         C.c_void_p(h_us.data_ptr()) if wl.stats else None, C.c_void_p(h_stego.data_ptr()))
         assert rc == 0, rc
-        rc = lib.tfft_extract_batch(hnd, n_img, C.c_void_p(h_stego.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data),
-                                    n_bits, 0.5, C.c_void_p(h_raw.data_ptr()))
+        rc = lib.tfft_extract_stream_batch(hnd, n_img, C.c_void_p(h_stego.data_ptr()), W, H, 0, C.c_void_p(bins.ctypes.data), len(bins), 0.5,
+                                           C.c_void_p(h_hdr2.data_ptr()), C.c_void_p(h_pay2.data_ptr()), wl.plen, C.c_void_p(h_st.data_ptr()), None)
         assert rc == 0, rc
     host_step()
     t0 = time.perf_counter()
@@ -477,8 +480,8 @@ def pcie_leg(wl, torch):
     return {"value": round(n_img * W * H / dt / 1e6, 1), "unit": "MPixels/s", "ms_per_step": round(dt * 1e3, 3),
             "with_cold_host_walk": round(n_img * W * H / (dt + wl.t_walk + wl.t_sort) / 1e6, 1),
             "stego_identical_to_resident_run": same,
-            "note": "pinned host buffers through tfft_embed_batch/tfft_extract_batch: H2D of covers and bits, kernels and D2H of stego/bits "
-                    "overlapped on three HIP streams"}
+            "note": "pinned host buffers through tfft_embed_stream_batch / tfft_extract_stream_batch: H2D of covers and packed stream bytes, "
+                    "kernels and D2H of stego / header / payload / status overlapped on three HIP streams"}
 
 
 def cpu_baseline(wl, S):

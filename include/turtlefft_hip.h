@@ -215,6 +215,15 @@ int tfft_embed_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int
                      uint64_t* usable_out /* or NULL */, uint8_t* rgb_out);
 int tfft_extract_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
                        uint64_t n_bits, double alpha, uint8_t* bits_out);
+/* ... and on packed bytes: 38 + payload_len bytes per image go in, 38 + clen + 16 bytes and a status word come out, instead of
+ * one byte per stream bit (the framing and the two-phase decode run on the device inside the same three-stream pipeline; semantics
+ * as tfft_*_stream_batch_dev; raw_bits_out may be NULL). */
+int tfft_embed_stream_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                            uint64_t n_bins, const uint8_t* header, const uint8_t* payload, uint64_t payload_len, double alpha,
+                            double rmin, double rmax, double magmin, uint64_t* usable_out /* or NULL */, uint8_t* rgb_out);
+int tfft_extract_stream_batch(tfft_ctx* ctx, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins,
+                              uint64_t n_bins, double alpha, uint8_t* header_out, uint8_t* payload_out, uint64_t max_payload_len,
+                              int32_t* status_out, uint8_t* raw_bits_out /* or NULL */);
 void* tfft_host_alloc(size_t bytes);
 void tfft_host_free(void* p);
 

@@ -56,6 +56,8 @@ SYMBOLS = {
     "tfft_host_alloc": (_vp, [C.c_size_t]),
     "tfft_host_free": (None, [_vp]),
     "tfft_plan_info": (_i, [_vp, _i, _i, _i, _pi]),
+    "tfft_embed_stream_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
+    "tfft_extract_stream_batch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp, _vp, _u64, _vp, _vp]),
     "tfft_embed_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _vp, _vp, _u64, _d, _d, _d, _d, _vp, _vp]),
     "tfft_extract_stream_batch_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _u64, _d, _vp, _vp, _u64, _vp, _vp]),
     "tfft_walk_create": (_i, [C.c_char_p, _i, _i, _d, _d, _d, C.POINTER(_vp)]),
@@ -355,6 +357,18 @@ class Context:
         n, h, w = rgb.shape[:3]
         _check(self.lib.tfft_extract_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), bits_out.shape[1], alpha,
                                            _ptr(bits_out)), "tfft_extract_batch")
+
+    def embed_stream_batch_host(self, rgb, bins, header, payload, out, usable=None, alpha=0.5, center=False, rmin=0.05, rmax=0.45, magmin=0.01):
+        n, h, w = rgb.shape[:3]
+        _check(self.lib.tfft_embed_stream_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), len(bins), _ptr(header), _ptr(payload),
+                                                payload.shape[1] if payload is not None else 0, alpha, rmin, rmax, magmin, _ptr(usable), _ptr(out)),
+               "tfft_embed_stream_batch")
+
+    def extract_stream_batch_host(self, rgb, bins, header_out, payload_out, status_out, raw_bits_out=None, alpha=0.5, center=False):
+        n, h, w = rgb.shape[:3]
+        _check(self.lib.tfft_extract_stream_batch(self.h, n, _ptr(rgb), w, h, int(center), _ptr(bins), len(bins), alpha, _ptr(header_out),
+                                                  _ptr(payload_out), payload_out.shape[1], _ptr(status_out), _ptr(raw_bits_out)),
+               "tfft_extract_stream_batch")
 
     def frame_expand_dev(self, n_images, header_ptr, payload_ptr, payload_len, bits_out_ptr):
         _check(self.lib.tfft_frame_expand_dev(self.h, n_images, _ptr(header_ptr), _ptr(payload_ptr), payload_len,

@@ -77,6 +77,7 @@ struct tfft_ctx {
     float dc_bias = 128.0f;               // constant taken out of the pixels before the forward transform and put back analytically (see
                                           // get_dc_table; both directions).  ON by default: it is what keeps every coefficient within the
                                           // 1e-4 relative tolerance on padded images.  TFFT_DC_BIAS=0 switches it off (A/B measurements only)
+    uint8_t* sio_hdr = nullptr; uint8_t* sio_pay = nullptr; int* sio_status = nullptr; uint64_t sio_plen = 0;      // host-buffer stream pipelines
     uint8_t* stream_bits = nullptr; unsigned* stream_plen = nullptr; size_t stream_cap = 0;   // tfft_*_stream_batch_dev: expanded / raw bits of a chunk
     void* stage_bins = nullptr; void* stage_bits = nullptr; void* stage_jit = nullptr; void* stage_out = nullptr;
     size_t stage_cap = 0;
@@ -536,6 +537,7 @@ int tfft_destroy(tfft_ctx* c) {
     for (auto& kv : c->dc) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
     (void)hipFree(c->out_pool); (void)hipFree(c->stream_bits); (void)hipFree(c->stream_plen);
+    (void)hipFree(c->sio_hdr); (void)hipFree(c->sio_pay); (void)hipFree(c->sio_status);
     for (int i = 0; i < 4; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1076,12 +1078,35 @@ static int pipe_init(tfft_ctx* c) {
     return dev_alloc(c, (void**)&c->out_pool, (size_t)c->n_slots * c->img_stride_b + 256);
 }
 
+// packed-byte framing around the host pipeline (tfft_*_stream_batch): header/payload bytes cross PCIe instead of one byte per bit
+struct StreamIO {
+    const uint8_t* header_in = nullptr; const uint8_t* payload_in = nullptr; uint64_t plen = 0;      // embed
+    uint8_t* header_out = nullptr; uint8_t* payload_out = nullptr; uint64_t max_plen = 0; int32_t* status_out = nullptr;   // extract
+};
+static int ensure_stream_io(tfft_ctx* c, uint64_t plen) {
+    if (c->sio_hdr && plen <= c->sio_plen) return TFFT_OK;
+    (void)hipStreamSynchronize(c->stream);
+    invalidate_graphs(c);
+    (void)hipFree(c->sio_hdr); (void)hipFree(c->sio_pay); (void)hipFree(c->sio_status);
+    c->sio_hdr = c->sio_pay = nullptr; c->sio_status = nullptr; c->sio_plen = 0;
+    const uint64_t cap = plen + plen / 4 + 64;
+    if (dev_alloc(c, (void**)&c->sio_hdr, (size_t)c->n_slots * 38) || dev_alloc(c, (void**)&c->sio_pay, (size_t)c->n_slots * cap) ||
+        dev_alloc(c, (void**)&c->sio_status, (size_t)c->n_slots * sizeof(int))) return TFFT_E_NOMEM;
+    c->sio_plen = cap;
+    return TFFT_OK;
+}
+
 static int batch_host(tfft_ctx* c, bool embed, int n_images, const uint8_t* rgb, int w, int h, int center,
                       const tfft_bin* bins, const uint8_t* bits, uint64_t n_bits, double alpha, double rmin, double rmax,
-                      double magmin, uint64_t* usable, uint8_t* rgb_out, uint8_t* bits_out) {
+                      double magmin, uint64_t* usable, uint8_t* rgb_out, uint8_t* bits_out, const StreamIO* sio = nullptr) {
     if (n_images == 0) return TFFT_OK;
     int rc = pipe_init(c);
     if (rc) return rc;
+    if (sio) {
+        rc = ensure_stream_io(c, embed ? sio->plen : sio->max_plen);
+        if (rc) return rc;
+        if (!c->stream_plen && dev_alloc(c, (void**)&c->stream_plen, (size_t)c->n_slots * sizeof(unsigned))) return TFFT_E_NOMEM;
+    }
     rc = ensure_stage(c, (uint64_t)c->n_slots * n_bits > n_bits ? (uint64_t)c->n_slots * n_bits : n_bits);
     if (rc) return rc;
     rc = batch_geometry(c, c->n_slots, w, h, center);
@@ -1102,23 +1127,40 @@ static int batch_host(tfft_ctx* c, bool embed, int n_images, const uint8_t* rgb,
         HIPCHK(c, hipStreamWaitEvent(c->s_in, c->ev_comp[hh], 0));
         // the pipeline treats the half's staging area as one packed batch buffer (g images back to back)
         HIPCHK(c, hipMemcpyAsync(c->img(s0), rgb + (size_t)i0 * img_bytes, (size_t)g * img_bytes, hipMemcpyHostToDevice, c->s_in));
-        if (embed) HIPCHK(c, hipMemcpyAsync(d_bits, bits + (size_t)i0 * n_bits, (size_t)g * n_bits, hipMemcpyHostToDevice, c->s_in));
+        if (embed && !sio) HIPCHK(c, hipMemcpyAsync(d_bits, bits + (size_t)i0 * n_bits, (size_t)g * n_bits, hipMemcpyHostToDevice, c->s_in));
+        if (embed && sio) {      // 38 + plen bytes per image instead of 912 + 56*plen
+            HIPCHK(c, hipMemcpyAsync(c->sio_hdr + (size_t)s0 * 38, sio->header_in + (size_t)i0 * 38, (size_t)g * 38, hipMemcpyHostToDevice, c->s_in));
+            if (sio->plen) HIPCHK(c, hipMemcpyAsync(c->sio_pay + (size_t)s0 * sio->plen, sio->payload_in + (size_t)i0 * sio->plen, (size_t)g * sio->plen, hipMemcpyHostToDevice, c->s_in));
+        }
         HIPCHK(c, hipEventRecord(c->ev_in[hh], c->s_in));
         // compute: needs the inputs, and the half's output buffers drained by the copy-out of two chunks ago
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[hh], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[hh], 0));
+        uint64_t limit = ~0ull;
+        if (embed && sio) {      // bits_from_bytes + rep3/rep7 on the device, image i's stream n_bits apart
+            limit = 38ull * 24 + sio->plen * 56;
+            HIPCHK(c, launch_frame_expand(c->sio_hdr + (size_t)s0 * 38, c->sio_pay + (size_t)s0 * sio->plen, sio->plen, g, d_bits, n_bits, c->stream));
+        }
         if (embed)
             rc = embed_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, d_bits, n_bits, alpha, rmin, rmax, magmin,
-                             usable ? c->usable + s0 : nullptr, c->out_pool + (size_t)s0 * c->img_stride_b, c->stream);   // packed, like the input
+                             usable ? c->usable + s0 : nullptr, c->out_pool + (size_t)s0 * c->img_stride_b, c->stream, limit);   // packed, like the input
         else
             rc = extract_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, n_bits, alpha, d_bout, c->stream);
         if (rc) return rc;
+        if (!embed && sio)       // header -> clen -> payload on the device: only packed bytes and a status word go back
+            HIPCHK(c, launch_stream_decode(d_bout, n_bits, sio->max_plen, g, c->sio_hdr + (size_t)s0 * 38, c->sio_pay + (size_t)s0 * sio->max_plen,
+                                           c->sio_status + s0, c->stream_plen + s0, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_comp[hh], c->stream));
         // copy-out
         HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_comp[hh], 0));
         if (embed) {
             HIPCHK(c, hipMemcpyAsync(rgb_out + (size_t)i0 * img_bytes, c->out_pool + (size_t)s0 * c->img_stride_b, (size_t)g * img_bytes, hipMemcpyDeviceToHost, c->s_out));
             if (usable) HIPCHK(c, hipMemcpyAsync(usable + i0, c->usable + s0, (size_t)g * sizeof(uint64_t), hipMemcpyDeviceToHost, c->s_out));
+        } else if (sio) {
+            HIPCHK(c, hipMemcpyAsync(sio->header_out + (size_t)i0 * 38, c->sio_hdr + (size_t)s0 * 38, (size_t)g * 38, hipMemcpyDeviceToHost, c->s_out));
+            if (sio->max_plen) HIPCHK(c, hipMemcpyAsync(sio->payload_out + (size_t)i0 * sio->max_plen, c->sio_pay + (size_t)s0 * sio->max_plen, (size_t)g * sio->max_plen, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(c, hipMemcpyAsync(sio->status_out + i0, c->sio_status + s0, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, c->s_out));
+            if (bits_out) HIPCHK(c, hipMemcpyAsync(bits_out + (size_t)i0 * n_bits, d_bout, (size_t)g * n_bits, hipMemcpyDeviceToHost, c->s_out));
         } else {
             HIPCHK(c, hipMemcpyAsync(bits_out + (size_t)i0 * n_bits, d_bout, (size_t)g * n_bits, hipMemcpyDeviceToHost, c->s_out));
         }
@@ -1138,6 +1180,21 @@ int tfft_extract_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w, int
                        uint64_t n_bits, double alpha, uint8_t* bits_out) {
     if (!c || n_images < 0 || !rgb || !bins || !bits_out || n_bits == 0) return TFFT_E_INVALID;
     return batch_host(c, false, n_images, rgb, w, h, center, bins, nullptr, n_bits, alpha, 0, 0, 0, nullptr, nullptr, bits_out);
+}
+int tfft_embed_stream_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins, uint64_t n_bins,
+                            const uint8_t* header, const uint8_t* payload, uint64_t payload_len, double alpha, double rmin, double rmax,
+                            double magmin, uint64_t* usable_out, uint8_t* rgb_out) {
+    if (!c || n_images < 0 || !rgb || !rgb_out || !bins || !header || (payload_len && !payload) || n_bins == 0) return TFFT_E_INVALID;
+    if (38ull * 24 + payload_len * 56 > n_bins) return TFFT_E_INVALID;
+    StreamIO io; io.header_in = header; io.payload_in = payload; io.plen = payload_len;
+    return batch_host(c, true, n_images, rgb, w, h, center, bins, nullptr, n_bins, alpha, rmin, rmax, magmin, usable_out, rgb_out, nullptr, &io);
+}
+int tfft_extract_stream_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w, int h, int center, const tfft_bin* bins, uint64_t n_bins,
+                              double alpha, uint8_t* header_out, uint8_t* payload_out, uint64_t max_payload_len, int32_t* status_out,
+                              uint8_t* raw_bits_out) {
+    if (!c || n_images < 0 || !rgb || !bins || n_bins == 0 || !header_out || !status_out || (max_payload_len && !payload_out)) return TFFT_E_INVALID;
+    StreamIO io; io.header_out = header_out; io.payload_out = payload_out; io.max_plen = max_payload_len; io.status_out = status_out;
+    return batch_host(c, false, n_images, rgb, w, h, center, bins, nullptr, n_bins, alpha, 0, 0, 0, nullptr, nullptr, raw_bits_out, &io);
 }
 void* tfft_host_alloc(size_t bytes) {
     void* p = nullptr;

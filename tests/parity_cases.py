@@ -587,6 +587,17 @@ def check_stream_batch(lib, orc, bufs, w, h, secrets=(40, 40, 40, 100, 100), slo
     # a walk shorter than the stream is refused at embed time; a walk shorter than what the header announces is status -3
     with pytest.raises(B.TfftError):
         ctx.embed_stream_batch_dev(1, bp, w, h, pb, n_bins, hop, pop, max_plen + 100, bp)
+    # the HOST-buffer variants (three-stream pipeline, packed bytes over PCIe) return the same bytes
+    members = groups[secrets[0]]
+    h_out = np.zeros_like(covers[members]); h_us = np.zeros(len(members), np.uint64)
+    ctx.embed_stream_batch_host(np.ascontiguousarray(covers[members]), ubins, np.ascontiguousarray(headers[members]),
+                                np.stack([payloads[m] for m in members]), h_out, usable=h_us)
+    assert np.array_equal(h_out, stego[members]) and (h_us >= 912 + 56 * (secrets[0] + 16)).all()
+    hh = np.zeros((nb, 38), np.uint8); hp = np.zeros((nb, max_plen), np.uint8); hs = np.zeros(nb, np.int32); hr = np.zeros((nb, n_bins), np.uint8)
+    ctx.extract_stream_batch_host(batch, ubins, hh, hp, hs, raw_bits_out=hr)
+    assert np.array_equal(hs, status) and np.array_equal(hh, hdr_out) and np.array_equal(hr, raw)
+    for i in range(nimg):
+        assert np.array_equal(hp[i, :secrets[i] + 16], payloads[i]), i
     ctx.close()
 
 
