@@ -2189,7 +2189,10 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     if (!force_fallback) {
         // fast path: sample histogram -> bracket -> one verified pass
         int step = PH / 128; if (step < 1) step = 1; if (step > 16) step = 16;      // sample every step-th row
-        unsigned nbs = (unsigned)((PH + step - 1) / step); if (nbs > nb) nbs = nb; if (nbs < 1) nbs = 1;
+        // sample pass: LDS-atomic bound (a block histograms its rows one element per atomic), so more and shorter blocks than the
+        // full passes get: 4 sampled rows per block, at most 32 blocks per plane (their ~150 non-zero buckets each go to global atomics)
+        unsigned nbs = (unsigned)((PH + step - 1) / step);
+        { unsigned cap = nb > 32u ? nb : 32u; unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < cap ? want : cap; }
         hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
         hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
