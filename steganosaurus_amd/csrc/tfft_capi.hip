@@ -87,6 +87,7 @@ struct tfft_ctx {
     int cols_direct_max_log = 8;          // PH <= 256: one column pass; taller: two-step N1 x N2 (a direct 512 pass reaches 1.8-3.4 TB/s, the two steps 5-6)
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
+    int cols_tiles_read = 16;             // the tile-resident read walks longer runs (A/B: 0.422 vs 0.455 ms per 32x1080p launch; the storing steps prefer 8)
     int median_force_fallback = 0;
 #ifndef TFFT_NO_GRAPHS
     // launch-bound calls (a few images): the launch sequence of a batch call is captured once into a hipGraph, keyed by every
@@ -214,7 +215,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; }
+                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
@@ -230,7 +231,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; }
+if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
             HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
@@ -496,6 +497,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
     c->own_stream = true;

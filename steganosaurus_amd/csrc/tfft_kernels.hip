@@ -808,18 +808,19 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // COLS_READ: the buckets of this workgroup's tiles are consecutive (tile is the last digit of the bucket id), so
     // nine offsets tell which tiles carry bins at all; a tile without bins (beyond the annulus: a tenth of them with
     // rmax = 0.45) is neither loaded nor transformed.  Workgroup-uniform, so the barriers stay aligned.
-    unsigned eoff[9];
+    constexpr int NOFF = 16;            // tiles per workgroup the skip test covers (the read variant walks 16, the others 8)
+    unsigned eoff[NOFF + 1];
     if (MODE == COLS_READ) {
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
 #pragma unroll
-        for (int i = 0; i < 9; i++) eoff[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
+        for (int i = 0; i <= NOFF; i++) eoff[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
     }
     auto has_bins = [&](int tile) -> bool {
-        if (MODE != COLS_READ || P.tiles_per_block > 8 || blockDim.z > 1) return true;
+        if (MODE != COLS_READ || P.tiles_per_block > NOFF || blockDim.z > 1) return true;
         const int i = tile - tile0;
         bool r = true;
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (k == i) r = eoff[k + 1] > eoff[k];
+        for (int k = 0; k < NOFF; k++) if (k == i) r = eoff[k + 1] > eoff[k];
         return r;
     };
     float2 u[E], un[E];
