@@ -52,39 +52,65 @@ void usage() {
             "  The 2-D FFT / phase embedding runs on an AMD MI355X through libturtlefft_hip.so.\n");
 }
 
-bool truthy(const std::string& v) { return v == "1" || v == "true"; }
+// ---- command line: one table row per option (the grammar, defaults and failure modes are the reference's, S:813-877: every
+// option takes exactly one value, unknown options print `Unknown arg: X` + usage, flags are "1" / "true")
+enum class OptKind { Text, Real, Flag, Count };
+struct OptSpec {
+    const char* name;
+    OptKind kind;
+    std::string Args::*text;          // Text
+    double Params::*real;             // Real
+    bool Params::*flag;               // Flag
+    uint32_t Params::*count;          // Count
+};
+const OptSpec kOptions[] = {
+    {"--in", OptKind::Text, &Args::inPath, nullptr, nullptr, nullptr},
+    {"--out", OptKind::Text, &Args::outPath, nullptr, nullptr, nullptr},
+    {"--secret", OptKind::Text, &Args::secret, nullptr, nullptr, nullptr},
+    {"--pass", OptKind::Text, &Args::pass, nullptr, nullptr, nullptr},
+    {"--key", OptKind::Text, &Args::keyBase64, nullptr, nullptr, nullptr},
+    {"--key-out", OptKind::Text, &Args::keyOutPath, nullptr, nullptr, nullptr},
+    {"--wrap-pass", OptKind::Text, &Args::wrapPass, nullptr, nullptr, nullptr},
+    {"--alpha", OptKind::Real, nullptr, &Params::alpha, nullptr, nullptr},
+    {"--jitter", OptKind::Real, nullptr, &Params::jitter, nullptr, nullptr},
+    {"--density", OptKind::Real, nullptr, &Params::density, nullptr, nullptr},
+    {"--rmin", OptKind::Real, nullptr, &Params::rmin, nullptr, nullptr},
+    {"--rmax", OptKind::Real, nullptr, &Params::rmax, nullptr, nullptr},
+    {"--magmin", OptKind::Real, nullptr, &Params::magmin, nullptr, nullptr},
+    {"--center", OptKind::Flag, nullptr, nullptr, &Params::center, nullptr},
+    {"--adaptive_alpha", OptKind::Flag, nullptr, nullptr, &Params::adaptive_alpha, nullptr},
+    {"--cover_dependent_path", OptKind::Flag, nullptr, nullptr, &Params::cover_dependent_path, nullptr},
+    {"--pbkdf2_iter", OptKind::Count, nullptr, nullptr, nullptr, &Params::pbkdf2_iter},
+};
 
-bool parse_args(int argc, char** argv, Args& A) {       // S:846-877
+const OptSpec* find_option(const char* name) {
+    for (const OptSpec& o : kOptions)
+        if (strcmp(o.name, name) == 0) return &o;
+    return nullptr;
+}
+
+bool parse_args(int argc, char** argv, Args& A) {
     if (argc < 2) return false;
     A.mode = argv[1];
-    for (int i = 2; i < argc; i++) {
-        const std::string k = argv[i];
-        auto need = [&]() { return (i + 1 >= argc) ? std::string() : std::string(argv[++i]); };
-        if (k == "--in") A.inPath = need();
-        else if (k == "--out") A.outPath = need();
-        else if (k == "--secret") A.secret = need();
-        else if (k == "--pass") A.pass = need();
-        else if (k == "--key") A.keyBase64 = need();
-        else if (k == "--key-out") A.keyOutPath = need();
-        else if (k == "--wrap-pass") A.wrapPass = need();
-        else if (k == "--alpha") A.P.alpha = std::stod(need());
-        else if (k == "--jitter") A.P.jitter = std::stod(need());
-        else if (k == "--density") A.P.density = std::stod(need());
-        else if (k == "--rmin") A.P.rmin = std::stod(need());
-        else if (k == "--rmax") A.P.rmax = std::stod(need());
-        else if (k == "--magmin") A.P.magmin = std::stod(need());
-        else if (k == "--center") A.P.center = truthy(need());
-        else if (k == "--pbkdf2_iter") A.P.pbkdf2_iter = (uint32_t)std::stoul(need());
-        else if (k == "--adaptive_alpha") A.P.adaptive_alpha = truthy(need());
-        else if (k == "--cover_dependent_path") A.P.cover_dependent_path = truthy(need());
-        else { fprintf(stderr, "Unknown arg: %s\n", k.c_str()); return false; }
+    int i = 2;
+    while (i < argc) {
+        const OptSpec* o = find_option(argv[i]);
+        if (!o) { fprintf(stderr, "Unknown arg: %s\n", argv[i]); return false; }
+        const std::string value = (i + 1 < argc) ? argv[i + 1] : "";      // a trailing option without a value reads as empty
+        i += 2;
+        switch (o->kind) {
+            case OptKind::Text: A.*(o->text) = value; break;
+            case OptKind::Real: A.P.*(o->real) = std::stod(value); break;               // throws on garbage: main() prints usage
+            case OptKind::Flag: A.P.*(o->flag) = (value == "1" || value == "true"); break;
+            case OptKind::Count: A.P.*(o->count) = (uint32_t)std::stoul(value); break;
+        }
     }
+    // what each mode cannot do without
+    const bool has_secret_source = !A.pass.empty() || !A.keyBase64.empty();
     if (A.mode == "gen-key") return true;
-    if (A.mode != "embed" && A.mode != "extract") return false;
-    if (A.inPath.empty()) return false;
-    if (A.pass.empty() && A.keyBase64.empty()) return false;
-    if (A.mode == "embed" && (A.outPath.empty() || A.secret.empty())) return false;
-    return true;
+    if (A.mode == "extract") return !A.inPath.empty() && has_secret_source;
+    if (A.mode == "embed") return !A.inPath.empty() && has_secret_source && !A.outPath.empty() && !A.secret.empty();
+    return false;
 }
 
 [[noreturn]] void die(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
