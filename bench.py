@@ -174,6 +174,9 @@ class Workload:
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if self.sort_bins:
             self.ctx.set_bit_index(d_index.cpu().numpy().astype(np.uint32))
+        # the bin list does not change between calls: let the extraction keep its per-tile buckets (tfft_bins_register_dev)
+        if os.environ.get("TFFT_BENCH_REGISTER_BINS", "1") != "0":
+            self.ctx.bins_register_dev(self.d_bins.data_ptr(), n_bins)
 
     def embed(self, n=None):
         n = n or self.n_img

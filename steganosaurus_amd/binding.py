@@ -70,6 +70,7 @@ SYMBOLS = {
     "tfft_audit_forward_rgb8_f64": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tfft_bins_sort": (_i, [_vp, _vp, _u64]),
     "tfft_set_bit_index": (_i, [_vp, _vp, _u64]),
+    "tfft_bins_register_dev": (_i, [_vp, _vp, _u64]),
     "tfft_profile_stage": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u64, _d, C.POINTER(C.c_float), _pi]),
     "tfft_timer_begin": (_i, [_vp]),
     "tfft_timer_end": (_i, [_vp, C.POINTER(C.c_float)]),
@@ -212,6 +213,9 @@ class Context:
             return
         idx = np.ascontiguousarray(bit_index, np.uint32)
         _check(self.lib.tfft_set_bit_index(self.h, _ptr(idx), len(idx)), "tfft_set_bit_index")
+
+    def bins_register_dev(self, bins_ptr, n):
+        _check(self.lib.tfft_bins_register_dev(self.h, _ptr(bins_ptr), n), "tfft_bins_register_dev")
 
     def plan_info(self, w, h, n_images=1):
         info = (C.c_int * 4)()

@@ -62,7 +62,11 @@ struct tfft_ctx {
     int* err = nullptr;                   // sticky bin-range flag
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
     // spectrum-free extraction (k_fft_cols<..., COLS_READ>): the bin list bucketed by column tile, per compute stream
-    struct TileBuckets { unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0; } tb[2];
+    struct TileBuckets { unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0;
+                         // what the buckets / the last-row scalar currently describe (tfft_bins_register_dev: reused while the registered list is the one passed in)
+                         const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr;
+                         const void* row_for = nullptr; uint64_t row_n = 0; int row_ph = 0, row_pw = 0; } tb[2];
+    const void* reg_bins = nullptr; uint64_t reg_n = 0;      // tfft_bins_register_dev
     const ColParams* fwd_read = nullptr;  // when set, the final forward column step runs in COLS_READ mode with these rd_* fields
     int tile_read = 1;                    // TFFT_TILE_READ=0: row-limited spectrum + k_read always; 1: tile read for chunks of >= 8 images; 3: always; 2: always, with the global-atomic bucket build
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
@@ -661,9 +665,19 @@ int tfft_lowfreq_mag(tfft_ctx* c, int slot, int region, double* out) {
     return TFFT_OK;
 }
 
+int tfft_bins_register_dev(tfft_ctx* c, const void* bins_dev, uint64_t n) {
+    if (!c) return TFFT_E_INVALID;
+    invalidate_graphs(c);      // a captured sequence may have left the bucket build out
+    for (auto& b : c->tb) { b.built_for = nullptr; b.row_for = nullptr; }
+    c->reg_bins = (bins_dev && n) ? bins_dev : nullptr;
+    c->reg_n = (bins_dev && n) ? n : 0;
+    return TFFT_OK;
+}
+
 int tfft_set_bit_index(tfft_ctx* c, const uint32_t* bit_index, uint64_t n) {
     if (!c) return TFFT_E_INVALID;
     invalidate_graphs(c);
+    for (auto& b : c->tb) { b.built_for = nullptr; b.row_for = nullptr; }
     if (!bit_index || n == 0) {            // back to "bins[i] carries bit i"
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->bit_index);
@@ -812,6 +826,7 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         invalidate_graphs(c);
+        b.built_for = nullptr;
         (void)hipFree(b.ent); b.ent = nullptr; b.cap = 0;
         const uint64_t cap = n + n / 4 + 1024;
         if (dev_alloc(c, (void**)&b.ent, cap * sizeof(TileBin))) return TFFT_E_NOMEM;
@@ -821,6 +836,7 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         invalidate_graphs(c);
+        b.built_for = nullptr;
         (void)hipFree(b.cnt); (void)hipFree(b.off); b.cnt = b.off = nullptr; b.nb_cap = 0;
         if (dev_alloc(c, (void**)&b.cnt, (size_t)(nb + 1) * sizeof(unsigned)) || dev_alloc(c, (void**)&b.off, (size_t)(nb + 1 + (nb + 1023) / 1024) * sizeof(unsigned)))
             return TFFT_E_NOMEM;
@@ -847,7 +863,12 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
         if (rc) return rc;
         auto& tb = c->tb[which];
         HIPCHK(c, hipMemsetAsync(bits_out, 0, (size_t)g * n_bits, st));          // bins the walk would never produce read as 0 (k_read does the same)
-        HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
+        const bool registered = bins == c->reg_bins && n_bits == c->reg_n;
+        if (!(registered && tb.built_for == bins && tb.built_n == n_bits && tb.built_ph == s.PH && tb.built_pw == s.PWi && tb.built_g == G &&
+              tb.built_index == c->bit_index)) {
+            HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
+            tb.built_for = registered ? bins : nullptr; tb.built_n = n_bits; tb.built_ph = s.PH; tb.built_pw = s.PWi; tb.built_g = G; tb.built_index = c->bit_index;
+        }
         ColParams rd{};
         rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.rd_jitter = nullptr;
         rd.rd_generic = ep.generic; rd.rd_ep = tb.ep;
@@ -859,7 +880,12 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
     } else {
         // the spectrum is only read at the bins of the list: rows above the highest one are never stored
         int* last_row = c->last_row + which;
-        HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
+        auto& tbr = c->tb[which];
+        const bool registered = bins == c->reg_bins && n_bits == c->reg_n;
+        if (!(registered && tbr.row_for == bins && tbr.row_n == n_bits && tbr.row_ph == s.PH && tbr.row_pw == s.PWi)) {
+            HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
+            tbr.row_for = registered ? bins : nullptr; tbr.row_n = n_bits; tbr.row_ph = s.PH; tbr.row_pw = s.PWi;
+        }
         c->fwd_last_row = last_row;
         rc = enqueue_forward(c, s0, g, rgb_in, st);
         c->fwd_last_row = nullptr;
@@ -1234,7 +1260,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     if (stage == ROWS_FWD && pl.fused_fwd && c->fuse_live && s.H < s.PH && (s.H % (s.PH >> 3)) != 0) launches = 2;      // one per live-row count
     {
         const bool compact = c->stats_compact && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
-        const bool finish1 = compact && (unsigned long long)s.PH * s.PWi <= (1ull << 22);
+        const bool finish1 = compact && (unsigned long long)s.PH * s.PWi <= (1ull << 22) && n_images <= 4;
         if (stage == MEDIANS) launches = compact ? (c->median_force_fallback ? 2 : (finish1 ? 5 : 7)) + (c->stats_fused ? 1 : 0)
                                                  : (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);
     }

@@ -2185,11 +2185,15 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     compact = compact && ((unsigned long long)PH * PW <= (1ull << 24));
     // the merged finish kernel walks a plane's candidates (~13 % of its bins) with ONE block: fine up to 2048^2 (270 k candidates),
     // too slow beyond (8 x 4K: 0.52 vs 0.43 ms for the whole statistics stage)
-    const bool finish1 = compact && ((unsigned long long)PH * PW <= (1ull << 22));
+    // ... and only worth it when the dependent-launch latency matters, i.e. for a few images: with 96 planes in flight the three
+    // parallel kernels take 35 us, the merged one 44
+    const bool finish1 = compact && ((unsigned long long)PH * PW <= (1ull << 22)) && n_images <= 4;
     if (!compact || force_fallback) hipLaunchKernelGGL(k_select_init, gs, dim3(256), 0, s, st, rank);
     if (!force_fallback) {
         // fast path: sample histogram -> bracket -> one verified pass
-        int step = PH / 128; if (step < 1) step = 1; if (step > 16) step = 16;      // sample every step-th row
+        // sample every step-th row, 64 rows in all (65 k stored values at 2048 columns: the sample median's standard error is
+        // ~0.6 % of the value, the bracket reaches 4.4 % to either side)
+        int step = PH / 64; if (step < 1) step = 1; if (step > 64) step = 64;
         // sample pass: LDS-atomic bound (a block histograms its rows one element per atomic), so more and shorter blocks than the
         // full passes get: 4 sampled rows per block, at most 32 blocks per plane (their ~150 non-zero buckets each go to global atomics)
         unsigned nbs = (unsigned)((PH + step - 1) / step);

@@ -584,6 +584,14 @@ def check_stream_batch(lib, orc, bufs, w, h, secrets=(40, 40, 40, 100, 100), slo
     ctx.extract_stream_batch_dev(nb, bp, w, h, pb, n_bins, hp3, pp3, max_plen, sp3)
     ctx.sync()
     assert np.array_equal(bufs.get(s3), status) and np.array_equal(bufs.get(h3), hdr_out) and np.array_equal(bufs.get(p3), pay_out)
+    # a registered bin list (tfft_bins_register_dev): what extraction derives from it is kept between calls -- same results, twice
+    ctx.bins_register_dev(pb, n_bins)
+    for _ in range(2):
+        r3, rp3 = bufs.put(np.zeros((nb, n_bins), np.uint8))
+        ctx.extract_batch_dev(nb, bp, w, h, pb, n_bins, rp3)
+        ctx.sync()
+        assert np.array_equal(bufs.get(r3), raw)
+    ctx.bins_register_dev(None, 0)
     # a walk shorter than the stream is refused at embed time; a walk shorter than what the header announces is status -3
     with pytest.raises(B.TfftError):
         ctx.embed_stream_batch_dev(1, bp, w, h, pb, n_bins, hop, pop, max_plen + 100, bp)
