@@ -1845,16 +1845,26 @@ __global__ void k_lowfreq_cols_f64(const double2* __restrict__ rowsum, int H, in
 // the stream.  Only packed bytes (38-byte header, ciphertext || tag) then cross PCIe.
 //   expand  : grid (ceil(n_bits/256), n_images);  majority: grid (ceil((38+plen)/256), n_images)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t i) {
+    uint64_t b; const uint8_t* src;
+    if (i < 912) { b = i / 3; src = header; }
+    else { b = (i - 912) / 7; src = payload; }
+    return (unsigned)((src[b >> 3] >> (7 - (b & 7))) & 1);
+}
+// one thread per FOUR stream bits (n = 912 + 56*plen is a multiple of 4): one dword store when the image's stream is 4-byte aligned
+// (one-byte stores were 16-28 us per call for a few MB)
 __global__ void k_frame_expand(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t plen,
                                uint8_t* __restrict__ bits, uint64_t stride) {
     const uint64_t n = 38ull * 24 + plen * 56;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     const uint64_t img = blockIdx.y;
-    uint64_t b; const uint8_t* src;
-    if (i < 912) { b = i / 3; src = header + img * 38; }
-    else { b = (i - 912) / 7; src = payload + img * plen; }
-    bits[img * stride + i] = (uint8_t)((src[b >> 3] >> (7 - (b & 7))) & 1);
+    const uint8_t* h = header + img * 38;
+    const uint8_t* p = payload + img * plen;
+    const unsigned v = frame_bit(h, p, i) | (frame_bit(h, p, i + 1) << 8) | (frame_bit(h, p, i + 2) << 16) | (frame_bit(h, p, i + 3) << 24);
+    uint8_t* dst = bits + img * stride + i;
+    if (((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t*>(dst) = v;
+    else { dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); dst[3] = (uint8_t)(v >> 24); }
 }
 __global__ void k_frame_majority(const uint8_t* __restrict__ bits, uint64_t plen, uint8_t* __restrict__ header,
                                  uint8_t* __restrict__ payload) {
@@ -1936,7 +1946,7 @@ hipError_t launch_frame_expand(const uint8_t* header, const uint8_t* payload, ui
                                uint64_t stride, hipStream_t s) {
     const uint64_t n = 38ull * 24 + plen * 56;
     if (stride < n) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_frame_expand, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, header, payload, plen, bits, stride);
+    hipLaunchKernelGGL(k_frame_expand, dim3((unsigned)((n / 4 + 255) / 256), n_images), dim3(256), 0, s, header, payload, plen, bits, stride);
     return hipGetLastError();
 }
 hipError_t launch_frame_majority(const uint8_t* bits, uint64_t plen, int n_images, uint8_t* header, uint8_t* payload,
