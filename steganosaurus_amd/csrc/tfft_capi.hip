@@ -795,9 +795,10 @@ static int batch_geometry(tfft_ctx* c, int g, int w, int h, int center) {
 }
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
+struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
-                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull) {
+                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull, const FrameSrc* frame = nullptr) {
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     int rc = enqueue_forward(c, s0, g, rgb_in, st);
@@ -816,6 +817,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
     }
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
     if (limit < n_bits) ep.limit = limit;      // the stream is shorter than the bin list (image i's bits still n_bits apart)
+    if (frame) { ep.frame_hdr = frame->hdr; ep.frame_pay = frame->pay; ep.frame_plen = frame->plen; }
     HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
     return enqueue_inverse(c, s0, g, rgb_out, st);
 }
@@ -1023,12 +1025,11 @@ static int embed_stream_batch_dev_impl(tfft_ctx* c, int n_images, const void* rg
         const int g = (n_images - i0 < c->n_slots) ? n_images - i0 : c->n_slots;
         rc = batch_geometry(c, g, w, h, center);
         if (rc) return rc;
-        // bits_from_bytes + rep3/rep7_encode on the device: image i's stream at stream_bits + i*n_bins
-        HIPCHK(c, launch_frame_expand((const uint8_t*)header_dev + (size_t)i0 * 38, (const uint8_t*)payload_dev + (size_t)i0 * payload_len, payload_len, g,
-                                      c->stream_bits, n_bins, c->stream));
-        rc = embed_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, c->stream_bits, n_bins, alpha, rmin, rmax,
+        // bits_from_bytes + rep3/rep7_encode happen inside k_embed: every bin computes its own stream bit from the packed frame
+        const FrameSrc fr{(const uint8_t*)header_dev + (size_t)i0 * 38, (const uint8_t*)payload_dev + (size_t)i0 * payload_len, payload_len};
+        rc = embed_chunk(c, 0, g, (const uint8_t*)rgb_dev + (size_t)i0 * img_bytes, (const tfft_bin*)bins_dev, nullptr, n_bins, alpha, rmin, rmax,
                          magmin, usable_out_dev ? (unsigned long long*)usable_out_dev + i0 : nullptr, (uint8_t*)rgb_out_dev + (size_t)i0 * img_bytes,
-                         c->stream, n_bits);
+                         c->stream, n_bits, &fr);
         if (rc) return rc;
     }
     return TFFT_OK;
@@ -1165,13 +1166,14 @@ static int batch_host(tfft_ctx* c, bool embed, int n_images, const uint8_t* rgb,
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[hh], 0));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[hh], 0));
         uint64_t limit = ~0ull;
-        if (embed && sio) {      // bits_from_bytes + rep3/rep7 on the device, image i's stream n_bits apart
+        FrameSrc fr{nullptr, nullptr, 0};
+        if (embed && sio) {      // bits_from_bytes + rep3/rep7 inside k_embed, from the packed frames of this part of the ring
             limit = 38ull * 24 + sio->plen * 56;
-            HIPCHK(c, launch_frame_expand(c->sio_hdr + (size_t)s0 * 38, c->sio_pay + (size_t)s0 * sio->plen, sio->plen, g, d_bits, n_bits, c->stream));
+            fr = FrameSrc{c->sio_hdr + (size_t)s0 * 38, c->sio_pay + (size_t)s0 * sio->plen, sio->plen};
         }
         if (embed)
-            rc = embed_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, d_bits, n_bits, alpha, rmin, rmax, magmin,
-                             usable ? c->usable + s0 : nullptr, c->out_pool + (size_t)s0 * c->img_stride_b, c->stream, limit);   // packed, like the input
+            rc = embed_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, sio ? nullptr : d_bits, n_bits, alpha, rmin, rmax, magmin,
+                             usable ? c->usable + s0 : nullptr, c->out_pool + (size_t)s0 * c->img_stride_b, c->stream, limit, sio ? &fr : nullptr);   // packed, like the input
         else
             rc = extract_chunk(c, s0, g, c->img(s0), (const tfft_bin*)c->stage_bins, n_bits, alpha, d_bout, c->stream);
         if (rc) return rc;

@@ -61,6 +61,8 @@ struct EmbedParams {
     size_t img_stride;     // float2 elements between images (grid.y = image)
     const uint32_t* bit_index;   // bins[i] carries stream bit bit_index[i] (nullptr: bit i); tfft_set_bit_index
     uint64_t limit;              // embed only: stream bits >= limit are not written (the stream is shorter than the bin list)
+    // embed only, stream pipelines: the bits come straight out of the packed frame (38-byte header, frame_plen payload bytes per image)
+    const uint8_t* frame_hdr; const uint8_t* frame_pay; uint64_t frame_plen;
 };
 
 struct CapParams {

@@ -952,6 +952,14 @@ __global__ void k_bins_last_row(const tfft_bin* __restrict__ bins, uint64_t n, i
     if (threadIdx.x == 0 && blk[0]) atomicMax(last_row, blk[0]);
 }
 
+// stream bit i of Rep-3(header, 38 bytes) || Rep-7(payload), MSB first (bits_from_bytes + rep3/rep7_encode, S:455-467, S:494-500)
+__device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t i) {
+    uint64_t b; const uint8_t* src;
+    if (i < 912) { b = i / 3; src = header; }
+    else { b = (i - 912) / 7; src = payload; }
+    return (unsigned)((src[b >> 3] >> (7 - (b & 7))) & 1);
+}
+
 // write_bit_on_bin S:712-732 over a bin list (the loop body of S:1074-1097).
 __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ bins, const uint8_t* __restrict__ bits,
                         const float* __restrict__ jitter, EmbedParams P, int* __restrict__ err) {
@@ -959,7 +967,7 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     if (i >= P.n) return;
     const int img = blockIdx.y;              // images of a batch share the bin list, not the bits
     spec += (size_t)img * P.img_stride;
-    bits += (size_t)img * P.n;
+    if (bits) bits += (size_t)img * P.n;
     const tfft_bin bn = bins[i];
     const uint64_t j = P.bit_index ? (uint64_t)P.bit_index[i] : i;      // the stream bit this bin carries
     if (j >= P.limit) return;                // the stream ends before this position of the walk (tfft_embed_stream_batch_dev)
@@ -971,7 +979,9 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
     const BinRef r = locate(p, y, x, P.PH, P.PW);
     const float2 v = spec[r.idx];
     const float mag = fmaxf(1e-12f, mag_of(v));
-    const int bit = bits[j];
+    // the stream pipelines hand over packed bytes: the bit is computed from them (a few KB per image, cache resident) instead of being
+    // read out of an expanded one-byte-per-bit copy at a scattered position
+    const int bit = P.frame_hdr ? (int)frame_bit(P.frame_hdr + (size_t)img * 38, P.frame_pay + (size_t)img * P.frame_plen, j) : (int)bits[j];
     float2 nv;
     if (!P.generic) {
         nv = make_float2(mag * P.cos_a, bit ? mag * P.sin_a : -mag * P.sin_a);
@@ -1845,12 +1855,6 @@ __global__ void k_lowfreq_cols_f64(const double2* __restrict__ rowsum, int H, in
 // the stream.  Only packed bytes (38-byte header, ciphertext || tag) then cross PCIe.
 //   expand  : grid (ceil(n_bits/256), n_images);  majority: grid (ceil((38+plen)/256), n_images)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t i) {
-    uint64_t b; const uint8_t* src;
-    if (i < 912) { b = i / 3; src = header; }
-    else { b = (i - 912) / 7; src = payload; }
-    return (unsigned)((src[b >> 3] >> (7 - (b & 7))) & 1);
-}
 // one thread per FOUR stream bits (n = 912 + 56*plen is a multiple of 4): one dword store when the image's stream is 4-byte aligned
 // (one-byte stores were 16-28 us per call for a few MB)
 __global__ void k_frame_expand(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t plen,
