@@ -76,6 +76,21 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
     bh = min(PH, int(0.45 * mn) + 1)
     bw = min(M, int(0.45 * mn) + 1)
     two_step = plan["two_step"]
+    delta = plan.get("delta", False)
+    if delta:
+        # delta embedding: stego = cover + IFFT(F' - F).  k_embed is replaced by k_gather_bits (entry 8 B, bit 1 B
+        # in, 1 B out); the last forward step also writes the listed bins' values (entry 8 B in, value 8 B out); the first inverse
+        # step reads entry + value + bit instead of the spectrum and only WRITES its planes; the row kernel also reads the cover
+        final_fwd = "cols_fwd_b" if two_step else "cols_fwd_a"
+        if stage == "embed":
+            return n_bits * (8 + 1 + 1)
+        if stage == final_fwd and not (plan["fused"] and stage == "cols_fwd_a"):
+            base = (6 * plane_full) if two_step else 3 * plane_h + 3 * plane_full
+            return base + n_bits * (8 + 8)
+        if stage == "cols_inv_a":
+            return (3 * plane_full if two_step else 3 * plane_h) + n_bits * (8 + 8 + 1)
+        if stage == "rows_inv":
+            return (3 * plane_full if plan["fused"] else 3 * plane_h) + 6 * img
     if plan["fused"]:
         # fused kernels: u8 <-> full half-plane in one launch; the H x M intermediate never exists
         if stage == "rows_fwd":
@@ -171,6 +186,7 @@ class Workload:
         self.slots = max(1, min(slots if slots > 0 else 32, n_img))
         self.ctx = S.Context(W, H, slots=self.slots, device=local)
         self.plan = self.ctx.plan_info(W, H, min(self.slots, n_img))      # which kernels a launch over the chunk takes
+        self.plan["delta"] = int(os.environ.get("TFFT_EMBED_DELTA", "1")) != 0      # the bin list is registered below: delta embedding applies
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if self.sort_bins:
             self.ctx.set_bit_index(d_index.cpu().numpy().astype(np.uint32))

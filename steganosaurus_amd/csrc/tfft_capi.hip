@@ -62,11 +62,16 @@ struct tfft_ctx {
     int* err = nullptr;                   // sticky bin-range flag
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
     // spectrum-free extraction (k_fft_cols<..., COLS_READ>): the bin list bucketed by column tile, per compute stream
-    struct TileBuckets { unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0;
+    struct TileBuckets { float2* fl = nullptr; uint8_t* pb = nullptr; uint64_t fl_cap = 0;      /* delta embedding: values of the listed bins, n_slots x n (ColParams::em_fl) */
+                         unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0;
                          // what the buckets / the last-row scalar currently describe (tfft_bins_register_dev: reused while the registered list is the one passed in)
                          const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr;
                          const void* row_for = nullptr; uint64_t row_n = 0; int row_ph = 0, row_pw = 0; } tb[2];
     const void* reg_bins = nullptr; uint64_t reg_n = 0;      // tfft_bins_register_dev
+    const ColParams* fwd_emit = nullptr;  // when set, the last forward column step also writes the values of the listed bins (COLS_EMIT, delta embedding)
+    const ColParams* inv_embed = nullptr; // when set, the first inverse column step runs in COLS_EMBED mode (delta embedding) with these rd_*/em_* fields
+    const uint8_t* inv_cover = nullptr;   // ... and the inverse row kernel adds its transform to these cover pixels
+    int embed_delta = 1;                  // batched embeds: stego = cover + IFFT(F' - F) (TFFT_EMBED_DELTA=0: write F' into the spectrum and invert it)
     const ColParams* fwd_read = nullptr;  // when set, the final forward column step runs in COLS_READ mode with these rd_* fields
     int tile_read = 1;                    // TFFT_TILE_READ=0: row-limited spectrum + k_read always; 1: tile read for chunks of >= 8 images; 3: always; 2: always, with the global-atomic bucket build
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
@@ -91,6 +96,8 @@ struct tfft_ctx {
     int cols_direct_max_log = 8;          // PH <= 256: one column pass; taller: two-step N1 x N2 (a direct 512 pass reaches 1.8-3.4 TB/s, the two steps 5-6)
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
+    int cols_tiles_embed = 0;             // delta embedding: tiles per workgroup of the first inverse step; 0 = 8 for columns up to 256, 2 from 512 on
+                                          // (A/B per 32 x 1080p launch: 0.40 / 0.45 / 0.51 / 0.49 ms with 8 / 4 / 2 / 1; per 8 x 4K: 0.58 / 0.56 / 0.54 with 8 / 2 / 1)
     int cols_tiles_read = 16;             // the tile-resident read walks longer runs (A/B: 0.422 vs 0.455 ms per 32x1080p launch; the storing steps prefer 8)
     int median_force_fallback = 0;
 #ifndef TFFT_NO_GRAPHS
@@ -189,6 +196,11 @@ enum Stage { ROWS_FWD = 0, COLS_FWD_A = 1, COLS_FWD_B = 2, EMBED = 3, COLS_INV_A
 int get_dc_table(tfft_ctx* c, int valid, int N, int center, int kind, double scale, const float2** out);
 void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw device pointers: dropped whenever a buffer is reallocated
 
+static void copy_embed_fields(ColParams& cp, const ColParams& e) {
+    cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off;
+    cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1;
+}
+
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
     const int M = s.PWi / 2;
@@ -203,7 +215,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
     cp.tiles_per_block = c->cols_tiles_per_block;
     switch (stage) {
         case ROWS_FWD: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->dc_bias};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, 0.f, c->slot_stride, c->dc_bias, nullptr};
             // rows + column step A; when some rows of the groups are padding, by the live-rows-only kernel (a full-height image has none)
             if (pl.fused_fwd && c->fuse_live && s.H < s.PH) HIPCHK(c, launch_rowcol_fwd_live(rgb_in, tmp, tw_w, tw_h, rp, n, st));
             else if (pl.fused_fwd) HIPCHK(c, launch_rowcol_fwd(rgb_in, tmp, tw_w, tw_h, rp, n, st));
@@ -220,6 +232,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
                 if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
+                else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
@@ -235,20 +248,23 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
+            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
+            else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
             HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-                if (c->dc_bias != 0.0f) {
+                if (c->inv_embed) { copy_embed_fields(cp, *c->inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 8); }
+                else if (c->dc_bias != 0.0f) {
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
                 }
                 HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
                 cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
-                if (c->dc_bias != 0.0f) {
+                if (c->inv_embed) { copy_embed_fields(cp, *c->inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 8); }
+                else if (c->dc_bias != 0.0f) {
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
                 }
@@ -262,7 +278,8 @@ if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp
             HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
-            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias};
+            RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias, nullptr};
+            if (c->inv_cover) { rp.cover = c->inv_cover; rp.bias = 0.f; }      // delta embedding: the transform of F' - F has no DC term to give back
             if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
             else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
@@ -493,6 +510,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_FUSE")) c->fuse = atoi(e);
     if (const char* e = getenv("TFFT_FUSE_WIDE")) c->fuse_wide = atoi(e);
     if (const char* e = getenv("TFFT_FUSE_LIVE")) c->fuse_live = atoi(e);
+    if (const char* e = getenv("TFFT_EMBED_DELTA")) c->embed_delta = atoi(e);
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
@@ -501,6 +519,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
@@ -538,7 +557,7 @@ int tfft_destroy(tfft_ctx* c) {
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
-    for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); }
+    for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->dc) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
@@ -794,35 +813,8 @@ static int batch_geometry(tfft_ctx* c, int g, int w, int h, int center) {
     return TFFT_OK;
 }
 
-// one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
-struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
-static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
-                       uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
-                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull, const FrameSrc* frame = nullptr) {
-    const Slot& s = c->slots[s0];
-    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
-    int rc = enqueue_forward(c, s0, g, rgb_in, st);
-    if (rc) return rc;
-    if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip: capacity is counted inside the median's full pass
-        CapParams p = cap_params(c, s, rmin, rmax);
-        p.magmin = magmin;
-        if (c->stats_fused && p.bw > 0) {
-            rc = enqueue_medians(c, s0, g, st, &p, usable);
-            if (rc) return rc;
-        } else {
-            rc = enqueue_medians(c, s0, g, st);
-            if (rc) return rc;
-            HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), usable, st));
-        }
-    }
-    EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
-    if (limit < n_bits) ep.limit = limit;      // the stream is shorter than the bin list (image i's bits still n_bits apart)
-    if (frame) { ep.frame_hdr = frame->hdr; ep.frame_pay = frame->pay; ep.frame_plen = frame->plen; }
-    HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
-    return enqueue_inverse(c, s0, g, rgb_out, st);
-}
 // device buffers of the tile buckets for `n` bins and `nb` buckets on compute stream `which`
-static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
+static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb, bool with_values = false) {
     auto& b = c->tb[which];
     if (n > b.cap || !b.ent) {
         (void)hipStreamSynchronize(c->stream);
@@ -845,9 +837,88 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb) {
         b.nb_cap = nb + 1;
     }
     if (!b.ep && dev_alloc(c, (void**)&b.ep, sizeof(EmbedParams))) return TFFT_E_NOMEM;
+    if (with_values && (n * (uint64_t)c->n_slots > b.fl_cap || !b.fl)) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        invalidate_graphs(c);
+        (void)hipFree(b.fl); (void)hipFree(b.pb); b.fl = nullptr; b.pb = nullptr; b.fl_cap = 0;
+        const uint64_t cap = (n + n / 4 + 1024) * (uint64_t)c->n_slots;
+        if (dev_alloc(c, (void**)&b.fl, cap * sizeof(float2)) || dev_alloc(c, (void**)&b.pb, cap)) return TFFT_E_NOMEM;
+        b.fl_cap = cap;
+    }
     return TFFT_OK;
 }
 
+// the bins of a list bucketed by (plane, group, column tile) for the tile-resident read and the delta embedding; a registered list
+// (tfft_bins_register_dev) keeps its buckets from one call to the next
+static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t n_bits, const Slot& s, int G, hipStream_t st) {
+    auto& tb = c->tb[which];
+    const bool registered = bins == c->reg_bins && n_bits == c->reg_n;
+    if (!(registered && tb.built_for == bins && tb.built_n == n_bits && tb.built_ph == s.PH && tb.built_pw == s.PWi && tb.built_g == G &&
+          tb.built_index == c->bit_index)) {
+        HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
+        tb.built_for = registered ? bins : nullptr; tb.built_n = n_bits; tb.built_ph = s.PH; tb.built_pw = s.PWi; tb.built_g = G; tb.built_index = c->bit_index;
+    }
+    return TFFT_OK;
+}
+
+// one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
+struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
+static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
+                       uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                       unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull, const FrameSrc* frame = nullptr) {
+    const Slot& s = c->slots[s0];
+    if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+    EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+    if (limit < n_bits) ep.limit = limit;      // the stream is shorter than the bin list (image i's bits still n_bits apart)
+    if (frame) { ep.frame_hdr = frame->hdr; ep.frame_pay = frame->pay; ep.frame_plen = frame->plen; }
+    // Delta embedding.  The inverse transform is linear and IFFT(F) is the cover itself, so the stego image is cover + IFFT(F' - F),
+    // and F' - F is zero but for the bins of the list.  The bins are bucketed by column tile (the buckets extraction uses); the last
+    // forward column step, which has every tile in LDS, writes the values of the listed bins out in bucket order; the first inverse
+    // column step builds its tiles from that list instead of reading the spectrum; nothing writes F' anywhere, and the row kernel adds
+    // its result to the cover's pixels.  (The bucket build is per call unless the list is registered, tfft_bins_register_dev.)
+    const bool delta = c->embed_delta && !ep.generic && n_bits > 0;      // whatever the chunk size: the bytes of a stego image do not depend on how the batch was cut
+    const int which = (c->stream2 && st == c->stream2) ? 1 : 0;
+    ColParams em{};
+    int rc;
+    if (delta) {
+        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+        const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16, nb = 3 * ntiles * G;
+        rc = ensure_buckets(c, which, n_bits, nb, true);
+        if (rc) return rc;
+        rc = build_buckets(c, which, bins, n_bits, s, G, st);
+        if (rc) return rc;
+        auto& tb = c->tb[which];
+        em.rd_bins = tb.ent; em.rd_off = tb.off; em.em_fl = tb.fl + (size_t)s0 * n_bits; em.em_pb = tb.pb + (size_t)s0 * n_bits;
+        em.em_n = n_bits; em.em_cos = ep.cos_a; em.em_sin = ep.sin_a;
+        // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way)
+        HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
+        c->fwd_emit = &em;
+    }
+    rc = enqueue_forward(c, s0, g, rgb_in, st);
+    c->fwd_emit = nullptr;
+    if (rc) return rc;
+    if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip: capacity is counted inside the median's full pass
+        CapParams p = cap_params(c, s, rmin, rmax);
+        p.magmin = magmin;
+        if (c->stats_fused && p.bw > 0) {
+            rc = enqueue_medians(c, s0, g, st, &p, usable);
+            if (rc) return rc;
+        } else {
+            rc = enqueue_medians(c, s0, g, st);
+            if (rc) return rc;
+            HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), usable, st));
+        }
+    }
+    if (delta) {
+        c->inv_embed = &em; c->inv_cover = rgb_in;
+        rc = enqueue_inverse(c, s0, g, rgb_out, st);
+        c->inv_embed = nullptr; c->inv_cover = nullptr;
+        return rc;
+    }
+    HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
+    return enqueue_inverse(c, s0, g, rgb_out, st);
+}
 static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, uint64_t n_bits,
                          double alpha, uint8_t* bits_out, hipStream_t st) {
     const Slot& s = c->slots[s0];
@@ -865,12 +936,8 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
         if (rc) return rc;
         auto& tb = c->tb[which];
         HIPCHK(c, hipMemsetAsync(bits_out, 0, (size_t)g * n_bits, st));          // bins the walk would never produce read as 0 (k_read does the same)
-        const bool registered = bins == c->reg_bins && n_bits == c->reg_n;
-        if (!(registered && tb.built_for == bins && tb.built_n == n_bits && tb.built_ph == s.PH && tb.built_pw == s.PWi && tb.built_g == G &&
-              tb.built_index == c->bit_index)) {
-            HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
-            tb.built_for = registered ? bins : nullptr; tb.built_n = n_bits; tb.built_ph = s.PH; tb.built_pw = s.PWi; tb.built_g = G; tb.built_index = c->bit_index;
-        }
+        rc = build_buckets(c, which, bins, n_bits, s, G, st);
+        if (rc) return rc;
         ColParams rd{};
         rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.rd_jitter = nullptr;
         rd.rd_generic = ep.generic; rd.rd_ep = tb.ep;
@@ -1257,6 +1324,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     for (int i = 1; i < n_images; i++) c->slots[i] = s;
     const ColPlan pl = plan_cols(c, s.PH, s.PWi, n_images);
     int launches = 1;
+    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
     if ((stage == COLS_FWD_B || stage == COLS_INV_B) && pl.direct) launches = 0;
     if ((stage == COLS_FWD_A || stage == COLS_INV_B) && pl.fused_fwd) launches = 0;
     if (stage == ROWS_FWD && pl.fused_fwd && c->fuse_live && s.H < s.PH && (s.H % (s.PH >> 3)) != 0) launches = 2;      // one per live-row count
@@ -1267,7 +1335,14 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
                                                  : (c->median_force_fallback ? 7 : 13) + (c->stats_fused ? 3 : 0);
     }
     if (stage == CAPACITY) launches = c->stats_fused ? 0 : 2;      // fused: counted inside the medians' full pass
-    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
+    // delta embedding (see embed_chunk): the batched pipeline has no k_embed launch, its first inverse step builds the tiles from the
+    // bins and its row kernel adds the cover -- the stages are timed the way the pipeline runs them
+    bool delta = false;
+    if (c->embed_delta && bins_dev && n_bits > 0 && (stage == EMBED || stage == COLS_INV_A || stage == ROWS_INV || stage == final_fwd)) {
+        const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+        delta = !ep0.generic;
+    }
+
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
     if (launches == 0) return TFFT_OK;
@@ -1286,10 +1361,38 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
             HIPCHK(c, launch_bins_last_row((const tfft_bin*)bins_dev, n_bits, s.PH, s.PWi, c->last_row, c->stream));
         }
     }
+    ColParams em{};
+    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED) && delta && bits_dev) {
+        if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+        const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16;
+        int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G, true);
+        if (rc) return rc;
+        rc = build_buckets(c, 0, (const tfft_bin*)bins_dev, n_bits, s, G, c->stream);
+        if (rc) return rc;
+        const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
+        em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
+        em.em_cos = ep0.cos_a; em.em_sin = ep0.sin_a;
+    }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {
         int rc = TFFT_OK;
         switch (stage) {
+            case COLS_FWD_A:
+            case COLS_FWD_B:
+                if (em.rd_bins && stage == final_fwd) c->fwd_emit = &em;
+                rc = enqueue_fft_stage(c, 0, n_images, stage, (const uint8_t*)rgb_dev, nullptr, c->stream);
+                c->fwd_emit = nullptr;
+                break;
+            case COLS_INV_A:
+                if (em.rd_bins) c->inv_embed = &em;
+                rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, nullptr, c->stream);
+                c->inv_embed = nullptr;
+                break;
+            case ROWS_INV:
+                if (delta && rgb_dev) c->inv_cover = (const uint8_t*)rgb_dev;
+                rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, (uint8_t*)rgb_out_dev, c->stream);
+                c->inv_cover = nullptr;
+                break;
             case COLS_FWD_READ:
                 if (rd.rd_bins) c->fwd_read = &rd; else c->fwd_last_row = c->last_row;
                 rc = enqueue_fft_stage(c, 0, n_images, final_fwd, nullptr, nullptr, c->stream);
@@ -1297,6 +1400,11 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
                 break;
             case EMBED: {
                 if (!index_ok(c, n_bits)) return TFFT_E_STATE;
+                if (em.rd_bins) {      // delta embedding: what is left of the embed stage is the gather of the stream bits into bucket order
+                    const int G = pl.direct ? 1 : (1 << pl.log_n1), nb = 3 * ((s.PWi / 2 + 15) / 16) * G;
+                    HIPCHK(c, launch_gather_bits(c->tb[0].ent, c->tb[0].off + nb, (const uint8_t*)bits_dev, nullptr, nullptr, 0, n_bits, n_bits, n_images, c->tb[0].pb, c->stream));
+                    break;
+                }
                 EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
                 HIPCHK(c, launch_embed(c->spec(0), (const tfft_bin*)bins_dev, (const uint8_t*)bits_dev, nullptr, ep, n_images, c->err, c->stream));
                 break;

@@ -17,6 +17,8 @@ struct RowParams {
     size_t img_stride;   // float2 elements between consecutive images of a batch in tmp/spec
     float bias;          // forward only: subtracted from every pixel before the transform (its rank-1 transform is added
                          // back by the last column step, ColParams::dc_*); 0 = off
+    const uint8_t* cover;    // inverse only, delta embedding: the transform holds IFFT(F' - F) and the pixel is
+                             // clamp(round(cover + delta)) (images W*H*3 bytes apart, like the output); nullptr = off, bias is added
 };
 
 // a bin of the list, located inside its column tile: value at LDS row `k` (= y / G), column `c` (= x % 16)
@@ -38,6 +40,14 @@ struct ColParams {
     const float* rd_jitter;          // per stream bit, or nullptr
     const struct EmbedParams* rd_ep; // device copy of the read parameters (generic path only dereferences it)
     int rd_generic;
+    // delta embedding: the LAST forward step (COLS_EMIT) writes the values of the bucketed bins (rd_bins / rd_off as above) to em_fl
+    // in bucket order; the FIRST inverse step (COLS_EMBED) starts every tile as zeros and puts F' - F at those bins, F taken from
+    // em_fl (S:712-732 with a fixed alpha)
+    float2* em_fl;                   // em_n values per image, indexed like rd_bins
+    const uint8_t* em_pb;            // COLS_EMBED: em_n stream bits per image in the same order (k_gather_bits; 2 = not written)
+    uint64_t em_n;                   // list stride between images (the length of the bin list)
+    float em_cos, em_sin;
+    int em_on;
     // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
     // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off
     const float2* dc_ah;       // PH entries, the factor c included
@@ -129,6 +139,8 @@ hipError_t audit_load_rgb8_f64(const uint8_t* rgb_dev, int W, int H, int PW, int
 hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, uint64_t n, int PH, int PW, int G,
                               unsigned* cnt, unsigned* off, TileBin* out, int* err, int force_global, hipStream_t s);
 // highest stored row any bin of the list touches -> *last_row (device int, reset here)
+hipError_t launch_gather_bits(const TileBin* ent, const unsigned* n_ent, const uint8_t* bits, const uint8_t* hdr, const uint8_t* pay, uint64_t plen,
+                              uint64_t n, uint64_t limit, int n_images, uint8_t* out, hipStream_t s);
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);
 hipError_t launch_embed(float2* spec, const tfft_bin* bins, const uint8_t* bits, const float* jitter,
                         const EmbedParams& P, int n_images, int* err, hipStream_t s);

@@ -512,6 +512,14 @@ __global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_rowcol_fwd_live(cons
 // clamp(round(v), 0, 255) with C round() semantics (half away from zero, S:389) for the values that
 // survive the clamp: negatives go to 0 either way, so only v >= 0 needs exact half-up rounding
 // (v - trunc(v) is exact in fp32, unlike v + 0.5f).
+// a byte of the cover through an ALIGNED dword load (cover_word) decoded later (cover_pick): a wave's byte loads at a stride of 6
+// (pixel pairs of one plane) are gathers; as dwords they coalesce
+__device__ __forceinline__ uint32_t cover_word(const uint8_t* p) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+}
+__device__ __forceinline__ unsigned cover_pick(uint32_t w, const uint8_t* p) {
+    return (w >> (8u * (unsigned)(reinterpret_cast<uintptr_t>(p) & 3))) & 255u;
+}
 __device__ __forceinline__ unsigned quantise_u8(float v) {
     v = fminf(fmaxf(v, 0.0f), 255.0f);
     const float r = truncf(v);
@@ -560,9 +568,40 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     const int xa = px, xb = (px == 0) ? M / 2 : M - px;
     const float2 wsx = tw[px], wsh = tw[M / 2];
     const float2* src = in + (size_t)img * P.img_stride + (size_t)plane * P.PH * M + (size_t)n2 * M;
+    // delta embedding: the transform is added to the cover's pixels.  Their bytes are fetched in one batch BEFORE any store (a load
+    // after a store to a pointer that may alias it -- in-place embedding is allowed -- is not hoisted: 15 exposed round trips per row,
+    // 0.42 -> 0.79 ms), and by the one-wave-per-row variant before its row transform, whose registers allow it
+    const size_t pix0 = ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
+    const uint8_t* cov = P.cover ? P.cover + pix0 : nullptr;
+    // W % 4 == 0 and an aligned cover: a thread takes groups of 4 pixels = 12 contiguous bytes = 3 coalesced dwords (its plane's 4
+    // bytes are picked out of them); otherwise the two bytes of a pixel pair come out of the aligned dwords holding them
+    const bool cov4 = cov && (P.W & 3) == 0 && (reinterpret_cast<uintptr_t>(P.cover) & 3) == 0;
+    uint32_t cw[2 * E];                 // raw dwords (decoded where they are used)
+    auto load_cover = [&]() {
+        if (cov4) {
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(cov - plane);
+            const int last = (P.W >> 2) - 1;
+#pragma unroll
+            for (int i = 0; i < E / 2; i++) {
+                const int q = imin(t + i * T, last);                  // clamped: every load unconditional
+                cw[3 * i] = row[3 * q]; cw[3 * i + 1] = row[3 * q + 1]; cw[3 * i + 2] = row[3 * q + 2];
+            }
+        } else {
+            const int last = (P.W >> 1) - 1;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const uint8_t* a = cov + 6 * imin(t + i * T, last);
+                cw[2 * i] = cover_word(a);
+                cw[2 * i + 1] = cover_word(a + 3);
+            }
+        }
+    };
     float2 va[N1], vb[N1];
 #pragma unroll
     for (int k1 = 0; k1 < N1; k1++) { va[k1] = src[(size_t)k1 * N2 * M + xa]; vb[k1] = src[(size_t)k1 * N2 * M + xb]; }
+#ifndef TFFT_COVER_LATE
+    if (T == 64 && y < P.H && cov && (P.W & 1) == 0) load_cover();      // behind the column loads in the queue, consumed after the row transform
+#endif
     DftReg<N1, -1, 0, N1>::run(va);
     DftReg<N1, -1, 0, N1>::run(vb);
 #pragma unroll
@@ -586,6 +625,9 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     const bool live = y < P.H;          // wave uniform (a row is one or two whole waves)
     if constexpr (T == 64) {            // one wave per row: no workgroup barrier follows, padded rows are done
         if (!live) return;
+#ifdef TFFT_COVER_LATE
+        if (cov && (P.W & 1) == 0) load_cover();
+#endif
         WaveSync::sync();
         float2 u[E];
 #pragma unroll
@@ -612,19 +654,54 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     }
 
     // ---- quantise and store this plane's bytes of row y
-    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)P.W * 3 + plane;
+    uint8_t* dst = rgb + pix0;
     if ((P.W & 1) == 0) {
         const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
-        for (int m = t; m < (P.W >> 1); m += T) {
-            const float2 v = lds[lay.idx(m, n1)];
-            dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
-            dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
+        if (cov && T != 64) load_cover();
+        if (cov4) {
+            const unsigned sh = 8u * (unsigned)plane;
+#pragma unroll
+            for (int i = 0; i < E / 2; i++) {
+                const int q = t + i * T;
+                if (q < (P.W >> 2)) {
+                    const uint32_t w0 = cw[3 * i], w1 = cw[3 * i + 1], w2 = cw[3 * i + 2];
+                    // bytes 3j + plane of the 12: pixel j's sample of this plane
+                    const uint32_t x0 = w0, x1 = (w0 >> 24) | (w1 << 8), x2 = (w1 >> 16) | (w2 << 16), x3 = w2 >> 8;
+                    const float2 va = lds[lay.idx(2 * q, n1)], vb = lds[lay.idx(2 * q + 1, n1)];
+                    uint8_t* d = dst + 12 * q;
+                    d[0] = (uint8_t)quantise_u8(s0 * va.x + (float)((x0 >> sh) & 255u));
+                    d[3] = (uint8_t)quantise_u8(s1 * va.y + (float)((x1 >> sh) & 255u));
+                    d[6] = (uint8_t)quantise_u8(s0 * vb.x + (float)((x2 >> sh) & 255u));
+                    d[9] = (uint8_t)quantise_u8(s1 * vb.y + (float)((x3 >> sh) & 255u));
+                }
+            }
+        } else if (cov) {
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const int m = t + i * T;
+                if (m < (P.W >> 1)) {
+                    const float2 v = lds[lay.idx(m, n1)];
+#ifdef TFFT_DBG_NOSTORE_ROWS
+                    if (v.x == 1.2345e30f)
+#endif
+                    {
+                    dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + (float)cover_pick(cw[2 * i], cov + 6 * m));
+                    dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + (float)cover_pick(cw[2 * i + 1], cov + 6 * m + 3));
+                    }
+                }
+            }
+        } else {
+            for (int m = t; m < (P.W >> 1); m += T) {
+                const float2 v = lds[lay.idx(m, n1)];
+                dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
+                dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
+            }
         }
     } else {
         for (int n = t; n < P.W; n += T) {
             float v = ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)];
             if (P.center && ((n + y) & 1)) v = -v;
-            dst[3 * n] = (uint8_t)quantise_u8(v + P.bias);
+            dst[3 * n] = (uint8_t)quantise_u8(v + (cov ? (float)cov[3 * n] : P.bias));
         }
     }
 }
@@ -690,19 +767,44 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
 
     // ---- quantise and store
     const int nbytes = P.W * 3;
-    uint8_t* dst = rgb + ((size_t)img * P.H + y) * (size_t)nbytes;
-    const bool fast = (PPB == 3) && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0);
+    const size_t row0 = ((size_t)img * P.H + y) * (size_t)nbytes;
+    uint8_t* dst = rgb + row0;
+    const uint8_t* cov = P.cover ? P.cover + row0 : nullptr;      // delta embedding: the transform is added to the cover's pixels
+    const bool fast = (PPB == 3) && ((P.W & 3) == 0) && (((uintptr_t)rgb & 3) == 0) && (((uintptr_t)P.cover & 3) == 0);
     if (fast) {
         const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
         uint32_t* dstw = reinterpret_cast<uint32_t*>(dst);
-        for (int g = tid; g < (P.W >> 2); g += nthr) {
+        const uint32_t* covw = reinterpret_cast<const uint32_t*>(cov);
+        // the cover's words of every group this thread stores, fetched before the first store (see k_colrow_inv)
+        constexpr int NG = imax(1, (M / 2 + T * PPB - 1) / (T * PPB));
+        uint32_t cw[3 * NG];
+        if (covw) {
+#pragma unroll
+            for (int i = 0; i < NG; i++) {
+                const int g = imin(tid + i * nthr, (P.W >> 2) - 1);      // clamped: every load unconditional
+                cw[3 * i] = covw[3 * g]; cw[3 * i + 1] = covw[3 * g + 1]; cw[3 * i + 2] = covw[3 * g + 2];
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            const int g = tid + gi * nthr;
+            if (g >= (P.W >> 2)) break;
             const int i0 = lay.idx(2 * g, 0), i1 = lay.idx(2 * g + 1, 0);
             const float2 r01 = lds[i0], r23 = lds[i1], g01 = lds[i0 + lay.pitch], g23 = lds[i1 + lay.pitch],
                          b01 = lds[i0 + 2 * lay.pitch], b23 = lds[i1 + 2 * lay.pitch];
-            const float bz = P.bias;      // DC removal: the constant taken out before the forward transform comes back here
-            const unsigned R0 = quantise_u8(s0 * r01.x + bz), R1 = quantise_u8(s1 * r01.y + bz), R2 = quantise_u8(s0 * r23.x + bz), R3 = quantise_u8(s1 * r23.y + bz);
-            const unsigned G0 = quantise_u8(s0 * g01.x + bz), G1 = quantise_u8(s1 * g01.y + bz), G2 = quantise_u8(s0 * g23.x + bz), G3 = quantise_u8(s1 * g23.y + bz);
-            const unsigned B0 = quantise_u8(s0 * b01.x + bz), B1 = quantise_u8(s1 * b01.y + bz), B2 = quantise_u8(s0 * b23.x + bz), B3 = quantise_u8(s1 * b23.y + bz);
+            // DC removal: the constant taken out before the forward transform comes back here (or the cover's own bytes, delta embedding)
+            float zR0, zG0, zB0, zR1, zG1, zB1, zR2, zG2, zB2, zR3, zG3, zB3;
+            if (covw) {
+                const uint32_t c0 = cw[3 * gi], c1 = cw[3 * gi + 1], c2 = cw[3 * gi + 2];
+                zR0 = (float)(c0 & 255u); zG0 = (float)((c0 >> 8) & 255u); zB0 = (float)((c0 >> 16) & 255u); zR1 = (float)(c0 >> 24);
+                zG1 = (float)(c1 & 255u); zB1 = (float)((c1 >> 8) & 255u); zR2 = (float)((c1 >> 16) & 255u); zG2 = (float)(c1 >> 24);
+                zB2 = (float)(c2 & 255u); zR3 = (float)((c2 >> 8) & 255u); zG3 = (float)((c2 >> 16) & 255u); zB3 = (float)(c2 >> 24);
+            } else {
+                zR0 = zG0 = zB0 = zR1 = zG1 = zB1 = zR2 = zG2 = zB2 = zR3 = zG3 = zB3 = P.bias;
+            }
+            const unsigned R0 = quantise_u8(s0 * r01.x + zR0), R1 = quantise_u8(s1 * r01.y + zR1), R2 = quantise_u8(s0 * r23.x + zR2), R3 = quantise_u8(s1 * r23.y + zR3);
+            const unsigned G0 = quantise_u8(s0 * g01.x + zG0), G1 = quantise_u8(s1 * g01.y + zG1), G2 = quantise_u8(s0 * g23.x + zG2), G3 = quantise_u8(s1 * g23.y + zG3);
+            const unsigned B0 = quantise_u8(s0 * b01.x + zB0), B1 = quantise_u8(s1 * b01.y + zB1), B2 = quantise_u8(s0 * b23.x + zB2), B3 = quantise_u8(s1 * b23.y + zB3);
             dstw[3 * g] = R0 | (G0 << 8) | (B0 << 16) | (R1 << 24);
             dstw[3 * g + 1] = G1 | (B1 << 8) | (R2 << 16) | (G2 << 24);
             dstw[3 * g + 2] = B2 | (R3 << 8) | (G3 << 16) | (B3 << 24);
@@ -712,7 +814,7 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
             const int n = off / 3, ch = off - 3 * n;
             float v = ldsf[2 * lay.idx(n >> 1, ch - plane0) + (n & 1)];
             if (P.center && ((n + y) & 1)) v = -v;
-            return quantise_u8(v + P.bias);
+            return quantise_u8(v + (cov ? (float)cov[off] : P.bias));
         };
         if (PPB == 3) {
             const int head = (int)((4 - ((uintptr_t)dst & 3)) & 3);
@@ -729,10 +831,23 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
             // byte loop below cost ~25 instructions per pixel (index division, single-float LDS reads) -- 30 % of this kernel's VALU work
             const float s0 = (P.center && (y & 1)) ? -1.0f : 1.0f, s1 = P.center ? -s0 : s0;
             uint8_t* d1 = dst + plane0;
-            for (int m = tid; m < (P.W >> 1); m += nthr) {
+            constexpr int NP = imax(1, (M + T * PPB - 1) / (T * PPB));
+            uint32_t cv[2 * NP];
+            if (cov) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const uint8_t* a = cov + plane0 + 6 * imin(tid + i * nthr, (P.W >> 1) - 1);
+                    cv[2 * i] = cover_word(a);
+                    cv[2 * i + 1] = cover_word(a + 3);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int m = tid + i * nthr;
+                if (m >= (P.W >> 1)) break;
                 const float2 v = lds[lay.idx(m, 0)];
-                d1[6 * m] = (uint8_t)quantise_u8(s0 * v.x + P.bias);
-                d1[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + P.bias);
+                d1[6 * m] = (uint8_t)quantise_u8(s0 * v.x + (cov ? (float)cover_pick(cv[2 * i], cov + plane0 + 6 * m) : P.bias));
+                d1[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + (cov ? (float)cover_pick(cv[2 * i + 1], cov + plane0 + 6 * m + 3) : P.bias));
             }
         } else {
             for (int n = tid; n < P.W; n += nthr) dst[3 * n + plane0] = (uint8_t)get(3 * n + plane0);
@@ -758,7 +873,12 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 //   COLS_ROWLIMIT  rows above *P.last_row_dev are not stored
 //   COLS_READ      extraction: nothing is stored at all -- the tile is parked in LDS and the bits of the bins
 //                  bucketed to it (P.rd_*) are read there (replaces the spectrum write + k_read's scattered reads)
-enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2 };
+//   COLS_EMBED     delta embedding (first inverse step): nothing is loaded -- the tile starts as zeros, receives F' - F at the bins
+//                  bucketed to it (F read from `in` at those bins only) and is transformed: the stego image is cover + IFFT(F' - F),
+//                  so neither k_embed's scattered read-modify-write nor this step's read of the whole spectrum takes place
+//   COLS_EMIT      delta embedding (last forward step): the transform, plus the values of the listed bins written to P.em_fl
+enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4 };
+__device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t i);   // defined with k_embed
 // DC: the DC-removal epilogue (ColParams::dc_*) is compiled in; its own instantiation, because the kernel sits at the
 // 256-VGPR cap and even the unused code costs accumulation-register spills
 // TW: the output twiddles of the two-step decomposition (P.tw_out) are compiled in: 32 VGPRs the final steps do not need
@@ -781,7 +901,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
     auto load_tile = [&](int tile, float2 (&v)[E]) {
         const int col = tile * C + c;
-        const bool active = (col < P.M) && (g < P.G);
+        const bool active = (col < P.M) && (g < P.G) && (MODE != COLS_EMBED);
         const float2* src = in + plane_off + col;
 #pragma unroll
         for (int m = 0; m < E; m++) {
@@ -828,7 +948,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
     auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
-    if (has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
+    if (MODE != COLS_EMBED && has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     // inter-pass twiddles: registers (fetched once per workgroup) for short columns; from TFFT_COLS_LDS_TW_LOG on the L-entry table
     // exp(+2 pi i j/L) is staged in LDS and read at the point of use (at L = 512 they would be 46 more VGPRs in a kernel capped at 256)
     constexpr bool TWL = (LOGL >= TFFT_COLS_LDS_TW_LOG);
@@ -842,8 +962,112 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     } else {
         fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
     }
+    // ---- delta embedding (COLS_EMIT in the last forward step, COLS_EMBED in the first inverse step) -------------------------------
+    // The stego image is cover + IFFT(F' - F), and F' - F is zero but at the bins of the list.  Reading F at those bins from the
+    // stored spectrum is 9 M scattered 8-byte reads per 32 x 1080p launch (0.25 ms inside the write-saturated inverse step; k_embed's
+    // read-modify-write cost 0.18 ms).  The last FORWARD step has every tile in LDS, so it writes the values of the tile's bins into a
+    // list in bucket order (em_fl, 8 bytes per bin per image, coalesced), k_gather_bits puts the stream bits in the same order (em_pb),
+    // and the inverse step builds its tiles from the three lists: bucket entry, value and bit are all addressed by the entry index,
+    // so the entries of tile i+1 are requested while tile i is transformed, like the tile loads of the other modes.
+    // NE entries per thread travel in registers; a longer bucket fetches the rest in place.
+    // Every fetch is UNCONDITIONAL at a clamped, always valid address, and nothing looks at a fetched word before the stage that uses
+    // it: a load inside a predicated block is followed by its own s_waitcnt vmcnt(0) (32 serialised round trips were seen).
+    constexpr int NE = 2;
+    struct EmEntry { TileBin tb; float2 f; unsigned bit, live; };   // bucket entry, the stored value of its bin (conjugate of the bin when
+                                                                    // tb.conj) and its stream bit (2: beyond the end of the stream)
+    EmEntry enC[NE], enN[NE];
+    const int em_tid = t * C + c, em_nthr = T * C;
+    // the bucket offsets of the workgroup's tiles (at most NOFF: the launcher sees to it) sit in LDS: read with lgkmcnt, not vmcnt,
+    // and without the branch trees a register array indexed by the tile turned into
+    unsigned* lds_eo = reinterpret_cast<unsigned*>(lds_tw + (TWL ? L : 0) + blockDim.z * C) + gl * (NOFF + 2);
+    if (MODE == COLS_EMBED || MODE == COLS_EMIT) {
+        const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
+        for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
+        __syncthreads();
+    }
+    auto em_range = [&](int tile, unsigned& e0, unsigned& e1) {
+        const int i = imin(tile - tile0, NOFF - 1);
+        e0 = lds_eo[i]; e1 = lds_eo[i + 1];
+        if (!(tile < tile1 && g < P.G)) e1 = e0;
+    };
+    const float2* em_fl = P.em_fl + (size_t)img * P.em_n;
+    const uint8_t* em_pb = P.em_pb + (size_t)img * P.em_n;
+    auto em_entries = [&](int tile, EmEntry (&en)[NE], bool with_value) {
+        unsigned e0, e1;
+        em_range(tile, e0, e1);
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const unsigned e = e0 + (unsigned)(em_tid + i * em_nthr);
+            en[i].live = e < e1 ? 1u : 0u;
+            const unsigned ec = en[i].live ? e : 0u;
+            en[i].tb = P.rd_bins[ec];
+            if (with_value) { en[i].f = em_fl[ec]; en[i].bit = em_pb[ec]; }
+        }
+    };
+    auto em_delta = [&](float2 f, unsigned bit, unsigned conj) -> float2 {      // write_bit_on_bin S:712-732 minus the old value
+        const float mag = fmaxf(1e-12f, mag_of(f));
+        float2 nv = make_float2(mag * P.em_cos, bit ? mag * P.em_sin : -mag * P.em_sin);
+        if (conj) nv = cconj(nv);
+        return csub(nv, f);
+    };
+    if (MODE == COLS_EMBED) em_entries(tile0, enC, true);
+    if (MODE == COLS_EMIT) em_entries(tile0, enC, false);
     for (int tile = tile0; tile < tile1; tile++) {
-        if (tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
+        if (MODE != COLS_EMBED && tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
+        if (MODE == COLS_EMIT) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
+        if (MODE == COLS_EMBED) {
+            // the tile of F' - F: zeros but for the bins of the list (S:712-732 per bin); a tile without bins is stored as zeros.
+            // The values of tile+1's bins and the entries of tile+2 are fetched now (see em_* above the loop).
+            bool hb = true;
+            if (blockDim.z == 1) { unsigned e0, e1; em_range(tile, e0, e1); hb = e1 > e0; }      // workgroup-uniform: the barriers stay aligned
+            em_entries(tile + 1, enN, true);
+            if (hb) {
+#pragma unroll
+                for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = make_float2(0.f, 0.f);
+                __syncthreads();
+#ifndef TFFT_DBG_NOENT
+#pragma unroll
+                for (int i = 0; i < NE; i++)
+                    if (enC[i].live && enC[i].bit < 2u) lds[lay.idx(enC[i].tb.k, enC[i].tb.c)] = em_delta(enC[i].f, enC[i].bit, enC[i].tb.conj);
+                if (g < P.G) {          // a bucket with more than NE entries per thread: the rest the slow way
+                    unsigned e0, e1;
+                    em_range(tile, e0, e1);
+                    for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) {
+                        const TileBin tb = P.rd_bins[e];
+                        const unsigned bit = em_pb[e];
+                        if (bit >= 2u) continue;
+                        lds[lay.idx(tb.k, tb.c)] = em_delta(em_fl[e], bit, tb.conj);
+                    }
+                }
+#endif
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, c)];
+                __syncthreads();            // before the first exchange of the transform overwrites the tile
+                if (TWL) fft_block_lazy<L, E, SIGN>(u, lds, lay, t, c, lds_tw, 1);
+                else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
+            }
+            const int col = tile * C + c;
+            if ((col < P.M) && (g < P.G)) {
+                float2* dst = out + plane_off + col;
+#pragma unroll
+                for (int m = 0; m < E; m++) {
+                    const int k = t + m * T;
+                    const int row = P.out_a * k + P.out_b * g;
+                    if (row < out_rows) {
+                        float2 v = hb ? u[m] : make_float2(0.f, 0.f);
+                        if (TW && hb) v = cmul(v, lds_wo[k]);
+#ifdef TFFT_DBG_NOSTORE
+                        if (v.x == 1.2345e30f)
+#endif
+                        dst[(size_t)row * P.M] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; i++) enC[i] = enN[i];
+            continue;
+        }
         if (!has_bins(tile)) {
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
@@ -898,6 +1122,38 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     dst[(size_t)row * P.M] = v;
                 }
             }
+        }
+        if (MODE == COLS_EMIT) {
+            // park the tile (as COLS_READ does) and write the values of the listed bins, DC term included, into the list the first
+            // inverse step embeds from: em_fl[entry index], coalesced
+            __syncthreads();            // the last gather of fft_block has been consumed by every thread
+#pragma unroll
+            for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
+            if (DC && t == 0) lds_aw[c] = awc;
+            __syncthreads();
+            {
+                unsigned e0, e1;
+                em_range(tile, e0, e1);
+                float2* fl = P.em_fl + (size_t)img * P.em_n;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    const TileBin tb = enC[i].tb;
+                    if (enC[i].live) {
+                        float2 v = lds[lay.idx(tb.k, tb.c)];
+                        if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
+                        fl[e0 + (unsigned)(em_tid + i * em_nthr)] = v;
+                    }
+                }
+                for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) {
+                    const TileBin tb = P.rd_bins[e];
+                    float2 v = lds[lay.idx(tb.k, tb.c)];
+                    if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
+                    fl[e] = v;
+                }
+            }
+            __syncthreads();            // before the next tile's exchanges overwrite the parked values
+#pragma unroll
+            for (int i = 0; i < NE; i++) enC[i] = enN[i];
         }
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = un[m];
@@ -992,6 +1248,20 @@ __global__ void k_embed(float2* __restrict__ spec, const tfft_bin* __restrict__ 
         nv = make_float2((float)((double)mag * cos(theta)), (float)((double)mag * sin(theta)));
     }
     spec[r.idx] = r.conj ? cconj(nv) : nv;    // the Hermitian mirror is implicit in the half spectrum
+}
+
+// delta embedding: the stream bits in bucket order, one byte per bucket entry and image (2: the stream ends before this position),
+// so that the first inverse column step reads entry, value and bit at the same index
+__global__ void k_gather_bits(const TileBin* __restrict__ ent, const unsigned* __restrict__ n_ent, const uint8_t* __restrict__ bits,
+                              const uint8_t* __restrict__ hdr, const uint8_t* __restrict__ pay, uint64_t plen, uint64_t n, uint64_t limit,
+                              uint8_t* __restrict__ out) {
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *n_ent) return;
+    const int img = blockIdx.y;
+    const uint64_t j = ent[e].bit;
+    unsigned b = 2u;
+    if (j < limit) b = hdr ? frame_bit(hdr + (size_t)img * 38, pay + (size_t)img * plen, j) : (unsigned)(bits[(size_t)img * n + j] & 1u);
+    out[(size_t)img * n + e] = (uint8_t)b;
 }
 
 // read_bit_from_bin S:734-746 for one (already conjugate-corrected) bin value
@@ -2100,37 +2370,50 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    const size_t lds = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
+    const size_t lds0 = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
                        (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0) + ((MODE == COLS_READ && DC) ? (size_t)gpb * C * sizeof(float2) : 0);
-    const int ntiles = (P.M + C - 1) / C, tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
+    const int ntiles = (P.M + C - 1) / C;
+    int tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
+    ColParams Q = P;
+    if (MODE == COLS_EMBED || MODE == COLS_EMIT) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
+        if (tpb > 16) tpb = 16;
+        Q.tiles_per_block = tpb;
+    }
+    const size_t lds = lds0 + ((MODE == COLS_EMBED || MODE == COLS_EMIT) ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0);
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, grid, block, lds, s, in, out, tw, P);
+    hipLaunchKernelGGL(k, grid, block, lds, s, in, out, tw, Q);
     return hipGetLastError();
 }
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s) {
     if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
-    if ((P.last_row_dev || P.rd_bins) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
+    if ((P.last_row_dev || (P.rd_bins && !P.em_on)) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
+    if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
+    if (P.em_on && !P.em_fl) return hipErrorInvalidValue;
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
              : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
 #define GI(n, DCF)                                                                      \
     (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, true>(in, out, tw_ph, P, n_planes, s) \
               : launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, false>(in, out, tw_ph, P, n_planes, s))
+#define GE(n)                                                                      \
+    (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_EMBED, false, true>(in, out, tw_ph, P, n_planes, s) \
+              : launch_cols_t<(n <= 10 ? n : 10), -1, COLS_EMBED, false, false>(in, out, tw_ph, P, n_planes, s))
 #define F(n)                                                                            \
-    return sign < 0 ? (P.dc_ah ? GI(n, true) : GI(n, false)) \
+    return sign < 0 ? (P.em_on ? GE(n) : P.dc_ah ? GI(n, true) : GI(n, false)) \
          : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
-         : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
+         : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
 #undef G
 #undef GI
+#undef GE
     return hipSuccess;
 }
 
@@ -2151,6 +2434,12 @@ hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, u
     hipLaunchKernelGGL(k_bucket_scan_b, dim3(1), dim3(1024), 1024 * sizeof(unsigned), s, totals, nblk, off, nb);
     hipLaunchKernelGGL(k_bucket_scan_c, dim3(nblk), dim3(1024), 0, s, off, totals, nb);
     hipLaunchKernelGGL(k_bucket_fill, dim3(blocks), dim3(256), lds, s, bins, bit_index, n, PH, PW, G, cnt, off, out, force_global);
+    return hipGetLastError();
+}
+hipError_t launch_gather_bits(const TileBin* ent, const unsigned* n_ent, const uint8_t* bits, const uint8_t* hdr, const uint8_t* pay, uint64_t plen,
+                              uint64_t n, uint64_t limit, int n_images, uint8_t* out, hipStream_t s) {
+    if (n == 0 || n_images == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_bits, dim3((unsigned)((n + 255) / 256), n_images), dim3(256), 0, s, ent, n_ent, bits, hdr, pay, plen, n, limit, out);
     return hipGetLastError();
 }
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s) {

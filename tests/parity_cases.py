@@ -609,6 +609,80 @@ def check_stream_batch(lib, orc, bufs, w, h, secrets=(40, 40, 40, 100, 100), slo
     ctx.close()
 
 
+def _ctx_with_env(env, *a, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return B.Context(*a, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, center=False, sort=True, lsb_frac=0.01, with_oracle=True):
+    """Batched embedding as the default pipeline runs it -- stego = cover + IFFT(F' - F), the first inverse column step building its
+    tiles from the bucketed bins (S:712-732 per bin, S:1099-1102 by linearity) -- against (a) the fp64 reference's stego image,
+    (b) the write-F'-then-invert pipeline (TFFT_EMBED_DELTA=0), and (c) the reference's reading of OUR stego image."""
+    P = Params(rmax=rmax, center=int(center))
+    ph, pw = orc.next_pow2(h), orc.next_pow2(w)
+    covers = np.stack([cover_rgb(w, h, 70 + i) for i in range(nimg)])
+    bits = np.random.default_rng(5).integers(0, 2, (nimg, n_bits)).astype(np.uint8)
+    bins = B.Walk(orc.subkeys(PK)[0], ph, pw, rmin=P.rmin, rmax=rmax, lib=lib).next(n_bits)
+    assert len(bins) == n_bits
+    ubins, idx = (B.bins_sort(bins, lib=lib) if sort else (bins, None))
+    kb, pb = bufs.put(ubins.view(np.uint8).reshape(-1, 8))
+    cb, pc = bufs.put(covers)
+    bb, pbits = bufs.put(bits)
+    out = {}
+    for mode in ("1", "0"):
+        ctx = _ctx_with_env({"TFFT_EMBED_DELTA": mode}, w, h, slots=max(1, nimg - 1), lib=lib)      # two chunks when nimg > 1
+        if idx is not None:
+            ctx.set_bit_index(idx)
+        ob, po = bufs.put(np.zeros_like(covers))
+        usable = np.zeros(nimg, np.uint64)
+        ub, pu = bufs.put(usable)
+        ctx.embed_batch_dev(nimg, pc, w, h, pb, pbits, n_bits, po, center=center, rmax=rmax, usable_ptr=pu)
+        ctx.sync()
+        out[mode] = (bufs.get(ob).copy(), bufs.get(ub).copy())
+        if mode == "1":      # the raw bits of our stego images, read by the batched extraction
+            rb, pr = bufs.put(np.zeros((nimg, n_bits), np.uint8))
+            ctx.extract_batch_dev(nimg, po, w, h, pb, n_bits, pr, center=center)
+            ctx.sync()
+            raw = bufs.get(rb).copy()
+        ctx.close()
+    (sd, ud), (s0, u0) = out["1"], out["0"]
+    assert np.array_equal(ud, u0)
+    assert np.array_equal(bufs.get(cb), covers), "the cover buffer is read, never written"
+    stats = []
+    for i in range(nimg):
+        dm = np.abs(sd[i].astype(np.int16) - s0[i])
+        assert dm.max() <= 1 and float((dm != 0).mean()) < lsb_frac, (i, dm.max(), float((dm != 0).mean()))
+        assert np.any(sd[i] != covers[i])
+        if not with_oracle:      # sizes the fp64 reference needs minutes for: the two pipelines against each other, and the round trip
+            assert float((raw[i] != bits[i]).mean()) < 0.02 or (ph, pw) != (h, w)
+            stats.append((None, float((dm != 0).mean())))
+            continue
+        want = orc.embed_rgb8(covers[i], PK, bits[i], P)[0]
+        dd = sd[i].astype(np.int16) - want
+        d0 = s0[i].astype(np.int16) - want
+        assert np.abs(dd).max() <= 1, ("delta stego differs from the fp64 reference by more than 1 LSB", i, np.abs(dd).max())
+        fd, f0 = float((dd != 0).mean()), float((d0 != 0).mean())
+        assert fd < lsb_frac, (i, fd)
+        assert np.abs(sd[i].astype(np.int16) - s0[i]).max() <= 1
+        stats.append((fd, f0))
+        want_raw = orc.extract_bits(sd[i], PK, n_bits, P)
+        bad = np.nonzero(raw[i] != want_raw)[0]
+        if len(bad):      # tolerable only where the reference's own decision is a coin flip
+            spec2, _ = orc.forward_rgb8(sd[i], P.center)
+            t = B.bins_to_triples(bins[bad])
+            v = spec2[t[:, 0], t[:, 1], t[:, 2]]
+            assert np.all(np.abs(v.imag) < 1e-5 * np.abs(v)), (i, len(bad), v[:4])
+    return stats
+
+
 def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0))):
     """Capacity counted inside the medians' full pass (batch path, S:998-1008) == tfft_capacity with thr = magmin * median,
     image by image, exactly: default annulus, an annulus that reaches into the mirror half (rmax > 0.5), thresholds at and

@@ -273,8 +273,11 @@ def test_batch_matches_single(lib, orc):
         assert one.capacity(0.01 * med) == int(usable[i])
         one.embed_bins(bins, bits[i])
         st = one.inverse_rgb8(w, h)
-        assert np.array_equal(st, out[i]), i
-        one.forward_rgb8(st)
+        # the single-image calls write F' into the spectrum and invert it, the batch embeds cover + IFFT(F' - F): one image in exact
+        # arithmetic, 1 LSB apart on a few pixels in fp32 (check_delta_embedding holds both to the fp64 reference)
+        dd = np.abs(st.astype(np.int16) - out[i])
+        assert dd.max() <= 1 and (dd != 0).mean() < 0.02, (i, dd.max(), (dd != 0).mean())
+        one.forward_rgb8(out[i])
         assert np.array_equal(one.read_bins(bins), raw[i]), i
     one.close()
     # bins in address order + bit index (+ the row-limited extraction forward), and the two-stream split:
@@ -532,10 +535,13 @@ def test_batch_1080p_against_oracle(lib, orc):
     ctx.close()
     one = B.Context(w, h, lib=lib)
     for i in (1, 17, 30):
+        # the single-image calls write F' into the spectrum and invert it; the batch embeds cover + IFFT(F' - F): the same image in
+        # exact arithmetic, 1 LSB apart on a few pixels in fp32 (both are held to the fp64 reference above)
         one.forward_rgb8(imgs[i]); one.embed_bins(bins, bits[i])
         st = one.inverse_rgb8(w, h)
-        assert np.array_equal(st, stego[i]), i
-        one.forward_rgb8(st)
+        dd = np.abs(st.astype(np.int16) - stego[i])
+        assert dd.max() <= 1 and (dd != 0).mean() < 1e-3, (i, dd.max(), (dd != 0).mean())
+        one.forward_rgb8(stego[i])
         assert np.array_equal(one.read_bins(bins), raw[i]), i
     one.close()
 
@@ -655,7 +661,24 @@ def test_wide_fused_batch_equals_forced_single(lib, orc):
         assert one.capacity(0.01 * one.medians()) == int(d_us[i].item())
         one.embed_bins(bins, bits[i])
         st = one.inverse_rgb8(w, h)
-        assert np.array_equal(st, d_out[i].cpu().numpy()), i
-        one.forward_rgb8(st)
+        got = d_out[i].cpu().numpy()
+        dd = np.abs(st.astype(np.int16) - got)      # write-then-invert (single image) against cover + IFFT(F' - F) (batch): 1 LSB on a few pixels
+        assert dd.max() <= 1 and (dd != 0).mean() < 1e-3, (i, dd.max(), (dd != 0).mean())
+        one.forward_rgb8(got)
         assert np.array_equal(one.read_bins(bins), d_raw[i].cpu().numpy()), i
     one.close()
+
+
+@pytest.mark.parametrize("case", [dict(w=200, h=120, n_bits=3000), dict(w=300, h=700, n_bits=6000, rmax=0.95), dict(w=2048, h=256, n_bits=20000, center=True),
+                                  dict(w=1920, h=1080, n_bits=n_stream_bits(4096), nimg=2), dict(w=3840, h=2160, n_bits=n_stream_bits(32768), nimg=2, sort=False)])
+def test_delta_embedding_against_oracle(lib, orc, case):
+    """The batched embed pipeline (stego = cover + IFFT(F' - F), tiles built from the bucketed bins) against the fp64 reference's stego
+    image, the write-then-invert pipeline and the reference's reading of our stego image: direct, two-step and both fused plans."""
+    stats = PC.check_delta_embedding(lib, orc, PC.TorchBufs, **case)
+    print("delta / write-then-invert fraction of pixels off the fp64 stego by 1 LSB:", case["w"], case["h"], stats)
+
+
+def test_delta_embedding_8192_three_pass(lib, orc):
+    """the three-pass plan (PW = 8192) at full size: the two embed pipelines agree to 1 LSB on < 0.1 % of the pixels"""
+    stats = PC.check_delta_embedding(lib, orc, PC.TorchBufs, 8192, 2048, n_stream_bits(4096), nimg=1, with_oracle=False, lsb_frac=1e-3)
+    print(stats)
