@@ -164,7 +164,13 @@ int tfft_audit_forward_rgb8_f64(tfft_ctx* ctx, const uint8_t* rgb, int w, int h,
  *   embed  : forward -> [medians+capacity when usable_out != NULL] -> embed -> inverse
  *   extract: forward -> read
  * usable_out (device, n uint64) receives each image's capacity so the caller
- * can raise "Message too large" (S:1009-1012) without a sync per image. */
+ * can raise "Message too large" (S:1009-1012) without a sync per image.
+ * The embed pipeline uses the linearity of S:1099-1103: stego = clamp(round(cover +
+ * IFFT(F' - F))), F' - F being zero but at the bins of the list -- the modified spectrum
+ * is never written, the cover buffer is read once more by the last kernel (in-place
+ * embedding, rgb_out_dev == rgb_dev, is allowed).  Same image as inverting F' in exact
+ * arithmetic; in fp32 it is 1 LSB away from what tfft_embed_bins + tfft_inverse_rgb8
+ * return on a few pixels per million (both within 1 LSB of the fp64 reference). */
 int tfft_embed_batch_dev(tfft_ctx* ctx, int n_images, const void* rgb_dev, int w, int h, int center,
                          const void* bins_dev, const void* bits_dev, uint64_t n_bits, double alpha,
                          double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev);

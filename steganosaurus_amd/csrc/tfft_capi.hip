@@ -54,6 +54,17 @@ struct tfft_ctx {
     float2* spec_pool = nullptr;
     float2* tmp_pool = nullptr;
     unsigned* cand_pool = nullptr;
+    float2* mini_pool = nullptr;          // [n_slots*3*max_ph*mini_cols] the sample of column tiles the tile statistics guess their bracket from
+    size_t mini_cols = 0;
+    float2* col0_pool = nullptr;          // [n_slots*3*max_ph] the packed column 0 as the COLS_STAT step leaves it
+    int stats_tile = 0;                   // TFFT_STATS_TILE=1: batched delta embeds run the statistics' bracket pass inside the last forward column
+                                          // step and never store the spectrum.  Measured SLOWER than storing it and running the statistics
+                                          // kernels over it (32 x 1080p: the step 0.75 vs 0.65 ms, the rest of the statistics 0.43 vs 0.41 ms;
+                                          // 8 x 4K: 0.98 vs 0.77 and 0.37 vs 0.40): the step is LDS/VALU bound, not store bound.  Kept as an option.
+    int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
+    int stats_tile_skew = 0;              // test hook: brackets moved by this many buckets (the fast path fails, the gated fallback runs)
+    const ColParams* fwd_plain_extra = nullptr;   // final forward step: tile_step / out_* (sample) or gate fields, and ...
+    float2* fwd_out_override = nullptr;           // ... its output buffer
     SelectState* sel = nullptr;           // [n_slots*3]
     float* med = nullptr;                 // [n_slots*3]
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS + n_slots]
@@ -199,6 +210,13 @@ void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw de
 static void copy_embed_fields(ColParams& cp, const ColParams& e) {
     cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off;
     cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1;
+    cp.st_sel = e.st_sel; cp.st_cand = e.st_cand; cp.st_cand_stride = e.st_cand_stride; cp.st_partial = e.st_partial; cp.st_amb = e.st_amb;
+    cp.st_col0 = e.st_col0; cp.st_slo = e.st_slo; cp.st_shi = e.st_shi; cp.st_cap = e.st_cap; cp.st_PW = e.st_PW;
+}
+
+static void copy_plain_extra(ColParams& cp, const ColParams& e) {
+    if (e.tile_step > 1) cp.tiles_per_block = 1;      // the sample: an eighth of the tiles, one per workgroup keeps the grid wide
+    cp.tile_step = e.tile_step; cp.tile_off = e.tile_off; cp.out_M = e.out_M; cp.out_plane_stride = e.out_plane_stride; cp.out_img_stride = e.out_img_stride; cp.gate = e.gate;
 }
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
@@ -233,7 +251,8 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             }
                 if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
                 else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
-                HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+                else if (c->fwd_plain_extra) copy_plain_extra(cp, *c->fwd_plain_extra);
+                HIPCHK(c, launch_cols(tmp, c->fwd_out_override ? c->fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
                 HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, +1, 3 * n, st));
@@ -250,7 +269,8 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             }
             if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
             else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
-            HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+            else if (c->fwd_plain_extra) copy_plain_extra(cp, *c->fwd_plain_extra);
+            HIPCHK(c, launch_cols(tmp, c->fwd_out_override ? c->fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
@@ -511,6 +531,9 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_FUSE_WIDE")) c->fuse_wide = atoi(e);
     if (const char* e = getenv("TFFT_FUSE_LIVE")) c->fuse_live = atoi(e);
     if (const char* e = getenv("TFFT_EMBED_DELTA")) c->embed_delta = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_TILE_SKEW")) c->stats_tile_skew = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
@@ -535,6 +558,9 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
+    c->mini_cols = M / 8 + 16;
+    if (!rc) rc = dev_alloc(c, (void**)&c->mini_pool, ns * 3 * (size_t)ph * c->mini_cols * sizeof(float2));
+    if (!rc) rc = dev_alloc(c, (void**)&c->col0_pool, ns * 3 * (size_t)ph * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
     if (!rc) rc = dev_alloc(c, (void**)&c->partial, (ns * 3 * TFFT_STAT_MAX_BLOCKS + ns) * sizeof(unsigned));      // + one flag per image (batch capacity)
@@ -556,6 +582,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipDeviceSynchronize();
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
+    (void)hipFree(c->mini_pool); (void)hipFree(c->col0_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
@@ -863,6 +890,69 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 }
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
+// forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
+// phases (tfft_profile_stage times them apart): 1 the steps before the last column step, 2 sample + bracket guess, 4 the COLS_STAT step,
+// 8 select + gated spectrum + fallbacks + capacity
+static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, hipStream_t st, ColParams& em, const CapParams& cap,
+                                     unsigned long long* usable, int phases = 15) {
+    const Slot& s = c->slots[s0];
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
+    // the sample: column tiles off, off + step, ..  -- centred in their strides (tiles 0, step, .. sit at the low-frequency end of every
+    // stride and read a median several per cent too high: the bracket missed on every padded image)
+    const int M = s.PWi / 2, ntiles = (M + 15) / 16, step = c->stats_tile_step;
+    const int off = ntiles > step / 2 ? step / 2 : 0;
+    const int Ms = 16 * ((ntiles - off + step - 1) / step);
+    if ((size_t)Ms > c->mini_cols) return TFFT_E_STATE;
+    int rc;
+    for (int stage : {ROWS_FWD, COLS_FWD_A}) {
+        if (stage == final_fwd || !(phases & 1)) break;
+        rc = enqueue_fft_stage(c, s0, g, stage, rgb_in, nullptr, st);
+        if (rc) return rc;
+    }
+    float2* mini = c->mini_pool + (size_t)s0 * 3 * s.PH * c->mini_cols;
+    float2* col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
+    SelectState* sel = c->sel + 3 * s0;
+    unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
+    float* amb = c->amb + (size_t)3 * s0 * TFFT_AMB_CAP;
+    unsigned* cand = c->cand_pool + (size_t)3 * s0 * c->cand_stride;
+    // (1) every step-th column tile -> a narrow spectrum; its histogram brackets the medians
+    ColParams ex{};
+    ex.tile_step = step; ex.tile_off = off; ex.out_M = Ms; ex.out_plane_stride = (size_t)s.PH * Ms; ex.out_img_stride = (size_t)3 * s.PH * Ms;
+    const ColParams* emit = c->fwd_emit;
+    if (phases & 2) {
+        c->fwd_emit = nullptr; c->fwd_plain_extra = &ex; c->fwd_out_override = mini;
+        rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
+        c->fwd_plain_extra = nullptr; c->fwd_out_override = nullptr; c->fwd_emit = emit;
+        if (rc) return rc;
+        HIPCHK(c, launch_stat_guess(mini, s.PH, s.PWi, Ms, ex.out_img_stride, g, sel, &cap, partial, off == 0 ? 1 : 0, st));
+        if (c->stats_tile_skew) HIPCHK(c, launch_skew_bracket(sel, g, c->stats_tile_skew, st));
+    }
+    // (2) the last forward step: values of the listed bins + the bracket pass on every value
+    if (phases & 4) {
+    em.st_sel = sel; em.st_cand = cand; em.st_cand_stride = c->cand_stride; em.st_partial = partial; em.st_amb = amb; em.st_col0 = col0;
+    em.st_slo = cap.s_lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_lo; em.st_shi = cap.s_hi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_hi;
+    em.st_cap = 1; em.st_PW = cap.PW;
+    c->fwd_emit = &em;
+    rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
+    c->fwd_emit = emit;
+    em.st_sel = nullptr;
+    if (rc) return rc;
+    }
+    if (!(phases & 8)) return TFFT_OK;
+    HIPCHK(c, launch_stat_select(s.PH, g, sel, cand, c->cand_stride, c->med + 3 * s0, col0, st));
+    // (3) images with a plane the fast path could not settle: their spectrum after all (the others return at once), then the fallbacks
+    ColParams gt{};
+    gt.gate = sel;
+    c->fwd_emit = nullptr; c->fwd_plain_extra = &gt;
+    rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
+    c->fwd_plain_extra = nullptr; c->fwd_emit = emit;
+    if (rc) return rc;
+    HIPCHK(c, launch_stat_settle(c->spec(s0), s.PH, s.PWi, c->slot_stride, g, sel, c->med + 3 * s0, &cap, partial, amb, usable, st));
+    for (int i = 0; i < g; i++) { c->slots[s0 + i].has_spec = false; c->slots[s0 + i].rgb_src = nullptr; }
+    return TFFT_OK;
+}
+
 struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
@@ -894,6 +984,22 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
         c->fwd_emit = &em;
+    }
+    if (delta && usable && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback) {
+        // the statistics' bracket pass inside the last forward column step: the spectrum is never stored (unless a plane's bracket
+        // turns out wrong: then the gated plain step produces it for the fallback kernels)
+        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+        CapParams p = cap_params(c, s, rmin, rmax);
+        p.magmin = magmin;
+        if (p.bw > 0 && pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24)) {
+            rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable);
+            c->fwd_emit = nullptr;
+            if (rc) return rc;
+            c->inv_embed = &em; c->inv_cover = rgb_in;
+            rc = enqueue_inverse(c, s0, g, rgb_out, st);
+            c->inv_embed = nullptr; c->inv_cover = nullptr;
+            return rc;
+        }
     }
     rc = enqueue_forward(c, s0, g, rgb_in, st);
     c->fwd_emit = nullptr;
@@ -1338,10 +1444,17 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     // delta embedding (see embed_chunk): the batched pipeline has no k_embed launch, its first inverse step builds the tiles from the
     // bins and its row kernel adds the cover -- the stages are timed the way the pipeline runs them
     bool delta = false;
-    if (c->embed_delta && bins_dev && n_bits > 0 && (stage == EMBED || stage == COLS_INV_A || stage == ROWS_INV || stage == final_fwd)) {
+    if (c->embed_delta && bins_dev && n_bits > 0 && (stage == EMBED || stage == COLS_INV_A || stage == ROWS_INV || stage == final_fwd || stage == MEDIANS)) {
         const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
         delta = !ep0.generic;
     }
+    // ... and their statistics run inside the last forward column step (enqueue_forward_tilestats): that step is timed as the pipeline
+    // runs it (final forward stage), everything else of the statistics under MEDIANS
+    CapParams tcap = cap_params(c, s, 0.05, 0.45);
+    tcap.magmin = 0.01;
+    const bool tile = delta && bits_dev && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback && tcap.bw > 0 &&
+                      pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
+    if (tile && stage == MEDIANS) launches = 11;       // sample step, histogram, guess (+ memset), 5 select kernels, gated step, fallback, settle
 
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
@@ -1362,7 +1475,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         }
     }
     ColParams em{};
-    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED) && delta && bits_dev) {
+    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED || (stage == MEDIANS && tile)) && delta && bits_dev) {
         if (!index_ok(c, n_bits)) return TFFT_E_STATE;
         const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16;
         int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G, true);
@@ -1372,6 +1485,25 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
         em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
         em.em_cos = ep0.cos_a; em.em_sin = ep0.sin_a;
+    }
+    if (tile && (stage == final_fwd || stage == MEDIANS)) {
+        float ms_all = 0.f, ms_c = 0.f;
+        int rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 2);      // a valid bracket for the timed step
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+        for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 4); if (rc) return rc; }
+        HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_t1));
+        HIPCHK(c, hipEventElapsedTime(&ms_c, c->ev_t0, c->ev_t1));
+        if (stage == MEDIANS) {      // the whole complex minus its COLS_STAT step
+            HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+            for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 14); if (rc) return rc; }
+            HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev_t1));
+            HIPCHK(c, hipEventElapsedTime(&ms_all, c->ev_t0, c->ev_t1));
+            *ms_per_rep = (ms_all - ms_c) / (float)reps;
+        } else *ms_per_rep = ms_c / (float)reps;
+        return TFFT_OK;
     }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {

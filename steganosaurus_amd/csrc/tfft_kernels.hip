@@ -599,9 +599,7 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     float2 va[N1], vb[N1];
 #pragma unroll
     for (int k1 = 0; k1 < N1; k1++) { va[k1] = src[(size_t)k1 * N2 * M + xa]; vb[k1] = src[(size_t)k1 * N2 * M + xb]; }
-#ifndef TFFT_COVER_LATE
-    if (T == 64 && y < P.H && cov && (P.W & 1) == 0) load_cover();      // behind the column loads in the queue, consumed after the row transform
-#endif
+    if (T == 64 && y < P.H && cov && (P.W & 1) == 0) load_cover();      // behind the column loads in the queue, consumed after the row transform (there: 0.51 vs 0.48 ms)
     DftReg<N1, -1, 0, N1>::run(va);
     DftReg<N1, -1, 0, N1>::run(vb);
 #pragma unroll
@@ -625,9 +623,6 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     const bool live = y < P.H;          // wave uniform (a row is one or two whole waves)
     if constexpr (T == 64) {            // one wave per row: no workgroup barrier follows, padded rows are done
         if (!live) return;
-#ifdef TFFT_COVER_LATE
-        if (cov && (P.W & 1) == 0) load_cover();
-#endif
         WaveSync::sync();
         float2 u[E];
 #pragma unroll
@@ -681,9 +676,6 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
                 const int m = t + i * T;
                 if (m < (P.W >> 1)) {
                     const float2 v = lds[lay.idx(m, n1)];
-#ifdef TFFT_DBG_NOSTORE_ROWS
-                    if (v.x == 1.2345e30f)
-#endif
                     {
                     dst[6 * m] = (uint8_t)quantise_u8(s0 * v.x + (float)cover_pick(cw[2 * i], cov + 6 * m));
                     dst[6 * m + 3] = (uint8_t)quantise_u8(s1 * v.y + (float)cover_pick(cw[2 * i + 1], cov + 6 * m + 3));
@@ -877,7 +869,11 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 //                  bucketed to it (F read from `in` at those bins only) and is transformed: the stego image is cover + IFFT(F' - F),
 //                  so neither k_embed's scattered read-modify-write nor this step's read of the whole spectrum takes place
 //   COLS_EMIT      delta embedding (last forward step): the transform, plus the values of the listed bins written to P.em_fl
-enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4 };
+//   COLS_STAT      COLS_EMIT without the spectrum store, with the statistics' bracket pass done on the values in registers (ColParams::st_*)
+enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4, COLS_STAT = 5 };
+__device__ __forceinline__ unsigned wave_rank_of(unsigned long long m) {       // rank of this lane among the set bits of a wave mask
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header, const uint8_t* __restrict__ payload, uint64_t i);   // defined with k_embed
 // DC: the DC-removal epilogue (ColParams::dc_*) is compiled in; its own instantiation, because the kernel sits at the
 // 256-VGPR cap and even the unused code costs accumulation-register spills
@@ -896,11 +892,18 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // A workgroup walks `tiles_per_block` adjacent 16-column tiles.  The twiddles depend on (t, g) only,
     // so they are fetched once; the next tile's data is fetched into registers while the current tile
     // is being transformed (the loads of tile i+1 overlap the LDS exchanges and stores of tile i).
+    if (MODE == COLS_PLAIN && SIGN > 0 && P.gate) {      // the statistics of this image were settled without the spectrum: nothing to redo
+        const SelectState* gs = P.gate + 3 * img;
+        if (gs[0].fast && gs[1].fast && gs[2].fast && gs[0].n_amb <= TFFT_AMB_CAP && gs[1].n_amb <= TFFT_AMB_CAP && gs[2].n_amb <= TFFT_AMB_CAP) return;
+    }
+    // COLS_PLAIN forward with tile_step > 1: tile index i stands for tile i*tile_step of the input and column block i of the output
+    const int ts = (MODE == COLS_PLAIN && SIGN > 0 && P.tile_step > 1) ? P.tile_step : 1;
     const int tile0 = blockIdx.x * P.tiles_per_block;
-    const int ntiles = (P.M + C - 1) / C;
+    const int toff = ts > 1 ? P.tile_off : 0;
+    const int ntiles = ((P.M + C - 1) / C - toff + ts - 1) / ts;
     const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
     auto load_tile = [&](int tile, float2 (&v)[E]) {
-        const int col = tile * C + c;
+        const int col = (tile * ts + toff) * C + c;
         const bool active = (col < P.M) && (g < P.G) && (MODE != COLS_EMBED);
         const float2* src = in + plane_off + col;
 #pragma unroll
@@ -947,7 +950,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
-    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    auto load_aw = [&](int tile) -> float2 { const int col = (tile * ts + toff) * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     if (MODE != COLS_EMBED && has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
     // inter-pass twiddles: registers (fetched once per workgroup) for short columns; from TFFT_COLS_LDS_TW_LOG on the L-entry table
     // exp(+2 pi i j/L) is staged in LDS and read at the point of use (at L = 512 they would be 46 more VGPRs in a kernel capped at 256)
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // the bucket offsets of the workgroup's tiles (at most NOFF: the launcher sees to it) sit in LDS: read with lgkmcnt, not vmcnt,
     // and without the branch trees a register array indexed by the tile turned into
     unsigned* lds_eo = reinterpret_cast<unsigned*>(lds_tw + (TWL ? L : 0) + blockDim.z * C) + gl * (NOFF + 2);
-    if (MODE == COLS_EMBED || MODE == COLS_EMIT) {
+    if (MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
         for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
         __syncthreads();
@@ -1010,11 +1013,65 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         if (conj) nv = cconj(nv);
         return csub(nv, f);
     };
+    // ---- COLS_STAT: k_collect_bracket's per-value work (see there) on this kernel's registers
+    const int st_lin = (gl * T + t) * C + c, st_wave = st_lin >> 6;
+    unsigned* st_wbuf = lds_eo + (blockDim.z - gl) * (NOFF + 2) + st_wave * 256;      // behind the offsets of all groups: 256 staged candidates per wave
+    unsigned* st_wcnt = lds_eo + (blockDim.z - gl) * (NOFF + 2) + ((blockDim.x * blockDim.y * blockDim.z) >> 6) * 256;      // [0] the workgroup's count, [1 + wave] a wave's list base
+    SelectState* st_s = (MODE == COLS_STAT) ? P.st_sel + 3 * img + plane : nullptr;
+    const unsigned st_lo = (MODE == COLS_STAT) ? st_s->lo : 0u, st_span = (MODE == COLS_STAT) ? st_s->hi - st_lo : 0u, st_base = st_lo << 19;
+    const float st_t2lo = (MODE == COLS_STAT) ? st_s->t2_lo : 0.f, st_t2hi = (MODE == COLS_STAT) ? st_s->t2_hi : 0.f;
+    unsigned* st_out = (MODE == COLS_STAT) ? P.st_cand + ((size_t)img * 3 + plane) * P.st_cand_stride : nullptr;
+    float* st_ambo = (MODE == COLS_STAT) ? P.st_amb + ((size_t)img * 3 + plane) * TFFT_AMB_CAP : nullptr;
+    unsigned st_below = 0, st_nstaged = 0, st_capcount = 0;
+    auto st_classify = [&](bool valid, unsigned b) {
+        const unsigned bk = b >> 19;
+        st_below += (valid && bk < st_lo) ? 2u : 0u;
+        const bool cnd = valid && (bk - st_lo) <= st_span;
+        const unsigned long long mk = __ballot(cnd);
+        if (mk) {                       // wave uniform
+            if (cnd) st_wbuf[st_nstaged + wave_rank_of(mk)] = (b - st_base) | 0x80000000u;
+            st_nstaged += (unsigned)__popcll(mk);
+        }
+    };
+    auto st_flush = [&]() {             // wave uniform: the wave's staged candidates go to the plane's list with one global atomic
+        const int lane = st_lin & 63;
+        WaveSync::sync();
+        if (lane == 0) st_wcnt[1 + st_wave] = atomicAdd(&st_s->n_cand, st_nstaged);
+        WaveSync::sync();
+        const unsigned gbase = st_wcnt[1 + st_wave];
+        for (unsigned i = lane; i < st_nstaged; i += 64) st_out[gbase + i] = st_wbuf[i];
+        WaveSync::sync();
+        st_nstaged = 0;
+    };
+    // the mirror bins ((PH-row)%PH, PW-colx) lie at columns > PW/2: inside the annulus only when it reaches beyond PW/2 (tall grids)
+    const bool st_mirror = (MODE == COLS_STAT) && (unsigned long long)(P.st_PW - P.M) * (unsigned long long)(P.st_PW - P.M) <= (unsigned long long)P.st_shi;
+    auto st_cap_elem = [&](int row, int colx, float m2) {
+        // the stored bin (row, colx), 0 < colx < M, stands for the full-grid bins (row, colx) and ((PH-row)%PH, PW-colx): each counts
+        // when it is off the axes and inside the annulus (S:698-700, S:998-1008)
+        unsigned w = 0;
+        if (row != 0 && 2 * row != P.PH) {
+            const unsigned d1 = (unsigned)row * (unsigned)row + (unsigned)colx * (unsigned)colx;
+            w = (d1 >= P.st_slo && d1 <= P.st_shi) ? 1u : 0u;
+            if (st_mirror) {
+                const unsigned ym = (unsigned)(P.PH - row), xm = (unsigned)(P.st_PW - colx);
+                const unsigned d2 = ym * ym + xm * xm;
+                w += (d2 >= P.st_slo && d2 <= P.st_shi) ? 1u : 0u;
+            }
+        }
+        if (!w) return;
+        if (!(m2 < st_t2hi)) st_capcount += w;
+        else if (w && !(m2 < st_t2lo)) {                     // rare: settled once the median is known
+            for (unsigned k = 0; k < w; k++) {
+                const unsigned slot = atomicAdd(&st_s->n_amb, 1u);
+                if (slot < TFFT_AMB_CAP) st_ambo[slot] = m2;
+            }
+        }
+    };
     if (MODE == COLS_EMBED) em_entries(tile0, enC, true);
-    if (MODE == COLS_EMIT) em_entries(tile0, enC, false);
+    if (MODE == COLS_EMIT || MODE == COLS_STAT) em_entries(tile0, enC, false);
     for (int tile = tile0; tile < tile1; tile++) {
         if (MODE != COLS_EMBED && tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
-        if (MODE == COLS_EMIT) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
+        if (MODE == COLS_EMIT || MODE == COLS_STAT) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
         if (MODE == COLS_EMBED) {
             // the tile of F' - F: zeros but for the bins of the list (S:712-732 per bin); a tile without bins is stored as zeros.
             // The values of tile+1's bins and the entries of tile+2 are fetched now (see em_* above the loop).
@@ -1025,7 +1082,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
 #pragma unroll
                 for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = make_float2(0.f, 0.f);
                 __syncthreads();
-#ifndef TFFT_DBG_NOENT
 #pragma unroll
                 for (int i = 0; i < NE; i++)
                     if (enC[i].live && enC[i].bit < 2u) lds[lay.idx(enC[i].tb.k, enC[i].tb.c)] = em_delta(enC[i].f, enC[i].bit, enC[i].tb.conj);
@@ -1039,7 +1095,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                         lds[lay.idx(tb.k, tb.c)] = em_delta(em_fl[e], bit, tb.conj);
                     }
                 }
-#endif
                 __syncthreads();
 #pragma unroll
                 for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, c)];
@@ -1057,9 +1112,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     if (row < out_rows) {
                         float2 v = hb ? u[m] : make_float2(0.f, 0.f);
                         if (TW && hb) v = cmul(v, lds_wo[k]);
-#ifdef TFFT_DBG_NOSTORE
-                        if (v.x == 1.2345e30f)
-#endif
                         dst[(size_t)row * P.M] = v;
                     }
                 }
@@ -1108,9 +1160,13 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             awc = awn;
             continue;
         }
-        const int col = tile * C + c;
-        if ((col < P.M) && (g < P.G)) {
-            float2* dst = out + plane_off + col;
+        const int col = (tile * ts + toff) * C + c;
+        if (MODE == COLS_STAT) {
+            // nothing is stored: the values are classified below, once the tile is parked in LDS
+        } else if ((col < P.M) && (g < P.G)) {
+            const int ocol = tile * C + c;
+            const int oM = ts > 1 ? P.out_M : P.M;
+            float2* dst = out + (ts > 1 ? (size_t)img * P.out_img_stride + (size_t)plane * P.out_plane_stride : plane_off) + ocol;
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const int k = t + m * T;
@@ -1119,11 +1175,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     float2 v = u[m];
                     if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
-                    dst[(size_t)row * P.M] = v;
+                    dst[(size_t)row * oM] = v;
                 }
             }
         }
-        if (MODE == COLS_EMIT) {
+        if (MODE == COLS_EMIT || MODE == COLS_STAT) {
             // park the tile (as COLS_READ does) and write the values of the listed bins, DC term included, into the list the first
             // inverse step embeds from: em_fl[entry index], coalesced
             __syncthreads();            // the last gather of fft_block has been consumed by every thread
@@ -1131,6 +1187,24 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             if (DC && t == 0) lds_aw[c] = awc;
             __syncthreads();
+            if (MODE == COLS_STAT) {
+                // the bracket pass of the statistics (k_collect_bracket's classify / cap_elem) on the parked tile: one value = one stored
+                // bin (row, col) of weight 2; the packed column 0 is left to k_col0_stats.  A rolled loop over LDS: unrolled over the
+                // registers it took the kernel to 256 VGPRs and 86 spilled SGPRs
+                const bool live = (col < P.M) && (g < P.G);
+#pragma unroll 2
+                for (int m = 0; m < E; m++) {
+                    const int k = t + m * T;
+                    const int row = P.out_a * k + P.out_b * g;
+                    float2 v = lds[lay.idx(k, c)];
+                    if (DC) v = cadd(v, cmul(lds_ah[k], awc));
+                    if (live && col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
+                    const float m2 = fmaf(v.x, v.x, v.y * v.y);
+                    st_classify(live && col != 0, __float_as_uint(m2));
+                    if (P.st_cap && live && col != 0) st_cap_elem(row, col, m2);
+                    if ((m & 1) && st_nstaged > 128) st_flush();        // at most 2 * 64 more before the next check: 256 slots
+                }
+            }
             {
                 unsigned e0, e1;
                 em_range(tile, e0, e1);
@@ -1158,6 +1232,19 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
 #pragma unroll
         for (int m = 0; m < E; m++) u[m] = un[m];
         awc = awn;
+    }
+    if (MODE == COLS_STAT) {
+        if (st_nstaged) st_flush();
+        if (st_below) atomicAdd(&st_s->below, (unsigned long long)st_below);
+        if (P.st_cap) {          // one count per workgroup
+            __syncthreads();
+            if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) st_wcnt[0] = 0;
+            __syncthreads();
+            if (st_capcount) atomicAdd(&st_wcnt[0], st_capcount);
+            __syncthreads();
+            if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0 && st_wcnt[0])
+                atomicAdd(&P.st_partial[((size_t)img * 3 + plane) * TFFT_STAT_MAX_BLOCKS + ((blockIdx.y * gridDim.x + blockIdx.x) % TFFT_STAT_MAX_BLOCKS)], st_wcnt[0]);
+        }
     }
 }
 
@@ -1462,8 +1549,8 @@ __device__ __forceinline__ SelectState* sel_of(SelectState* st) { return st + (s
 // instead of one per bin.
 __device__ __forceinline__ float mag2_of(float2 v) { return fmaf(v.x, v.x, v.y * v.y); }
 template <class F>
-__device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f) {
-    if (x == 0) {
+__device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f, bool col0_packed = true) {
+    if (x == 0 && col0_packed) {
         float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
         f(__float_as_uint(mag2_of(f0)), 1u); f(__float_as_uint(mag2_of(fm)), 1u);
     } else {
@@ -1473,7 +1560,7 @@ __device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int 
 
 // histogram of rows y0, y0+row_step, ... ; guarded != 0: fallback role, skip when the fast path succeeded
 __global__ void k_hist_spec(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
-                            SelectState* __restrict__ st, int row_step, int guarded) {
+                            SelectState* __restrict__ st, int row_step, int guarded, int col0_packed = 1) {
     SelectState* s = sel_of(st);
     if (guarded && s->done) return;
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 4096 counters
@@ -1482,7 +1569,7 @@ __global__ void k_hist_spec(const float2* __restrict__ spec, int PH, int M, size
     const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
     for (int y = blockIdx.x * row_step; y < PH; y += gridDim.x * row_step)
         for (int x = threadIdx.x; x < M; x += blockDim.x)
-            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); });
+            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); }, col0_packed != 0);
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
@@ -1834,6 +1921,45 @@ __global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __rest
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
+// statistics inside the last forward column step (COLS_STAT): what that kernel leaves to do.
+// (a) the packed column 0: F[y][0] and F[y][M] (unpack_col0), one value of weight 1 each, classified like k_collect_bracket does;
+//     neither column belongs to the annulus count (x = 0 and 2x = PW are excluded, S:698-700)
+__global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+    SelectState* s = st + (size_t)blockIdx.z * 3 + blockIdx.y;
+    const float2* cz = col0 + ((size_t)blockIdx.z * 3 + blockIdx.y) * PH;
+    unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    const unsigned lo = s->lo, span = s->hi - lo, base_bits = lo << 19;
+    unsigned below = 0;
+    for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < PH; y += gridDim.x * blockDim.x) {
+        const float2 a = cz[y], b = cz[(PH - y) & (PH - 1)];
+        const float2 f0 = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        const float2 fm = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+        const unsigned v[2] = {__float_as_uint(mag2_of(f0)), __float_as_uint(mag2_of(fm))};
+        for (int i = 0; i < 2; i++) {
+            const unsigned bk = v[i] >> 19;
+            if (bk < lo) below++;
+            else if (bk - lo <= span) out[atomicAdd(&s->n_cand, 1u)] = v[i] - base_bits;      // weight 1: bit 31 clear
+        }
+    }
+    if (below) atomicAdd(&s->below, (unsigned long long)below);
+}
+// (b) the level-2 histogram of the candidates (k_collect_bracket builds it while it stages them)
+__global__ void k_hist_cand2(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
+    SelectState* s = sel_of(st);
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const unsigned n = s->n_cand;
+    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned c = in[i], v = c & 0x7FFFFFFFu;
+        atomicAdd(&hist[(v >> 11) & 1023u], (c >> 31) ? 2u : 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
 }
 
@@ -2375,11 +2501,13 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const int ntiles = (P.M + C - 1) / C;
     int tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     ColParams Q = P;
-    if (MODE == COLS_EMBED || MODE == COLS_EMIT) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
+    if (MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
         if (tpb > 16) tpb = 16;
         Q.tiles_per_block = tpb;
     }
-    const size_t lds = lds0 + ((MODE == COLS_EMBED || MODE == COLS_EMIT) ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0);
+    const size_t nwaves = ((size_t)C * T * gpb + 63) / 64;
+    const size_t lds = lds0 + ((MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
+                       (MODE == COLS_STAT ? (nwaves * 257 + 1) * sizeof(unsigned) : 0);
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
     if (lds > 48 * 1024) {
@@ -2396,6 +2524,8 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
     if (P.em_on && !P.em_fl) return hipErrorInvalidValue;
+    if (P.st_sel && (!P.em_on || sign < 0 || logl > 9 || !P.st_cand || !P.st_col0 || (P.st_cap && (!P.st_partial || !P.st_amb)))) return hipErrorInvalidValue;
+    if ((P.tile_step > 1 || P.gate) && (sign < 0 || P.rd_bins || P.last_row_dev || P.tw_out)) return hipErrorInvalidValue;      // plain final forward step only
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
              : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
@@ -2408,7 +2538,7 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
 #define F(n)                                                                            \
     return sign < 0 ? (P.em_on ? GE(n) : P.dc_ah ? GI(n, true) : GI(n, false)) \
          : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
-         : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
+         : (P.em_on && P.st_sel) ? G(n, COLS_STAT) : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
 #undef G
@@ -2501,7 +2631,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         // full passes get: 4 sampled rows per block, at most 32 blocks per plane (their ~150 non-zero buckets each go to global atomics)
         unsigned nbs = (unsigned)((PH + step - 1) / step);
         { unsigned cap = nb > 32u ? nb : 32u; unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < cap ? want : cap; }
-        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0);
+        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0, 1);
         hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
         // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
@@ -2537,7 +2667,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         hipLaunchKernelGGL(k_median_fallback, gs, dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, force_fallback ? 1 : 0);
     } else {
         // fallback: plain three-level select; every block returns immediately when the fast path verified
-        hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1);
+        hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1, 1);
         hipLaunchKernelGGL(k_select<1>, gs, dim3(256), sel_lds, s, st, med_out);
         hipLaunchKernelGGL(k_collect, g3, dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M, img_stride, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
@@ -2554,6 +2684,59 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
             hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
             if (e != hipSuccess) return e;
         }
+    }
+    return hipGetLastError();
+}
+
+// test hook (TFFT_STATS_TILE_SKEW): move every bracket by `skew` level-1 buckets, so that the fast path fails and the gated fallback runs
+__global__ void k_skew_bracket(SelectState* __restrict__ st, int skew) {
+    SelectState* s = st + blockIdx.x;
+    if (threadIdx.x == 0) { s->lo = (unsigned)imax(0, imin(4093, (int)s->lo + skew)); s->hi = s->lo + 2; }
+}
+hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s) {
+    hipLaunchKernelGGL(k_skew_bracket, dim3(3 * n_images), dim3(64), 0, s, st, skew);
+    return hipGetLastError();
+}
+// ---- statistics inside the last forward column step (COLS_STAT): the launches around it.
+// (1) bracket guess from a sample of the column tiles (a narrow spectrum of Ms columns written by the plain step with tile_step)
+hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t mini_img_stride, int n_images, SelectState* st, const CapParams* cap,
+                             unsigned* partial, int col0_packed, hipStream_t s) {
+    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
+    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    hipError_t e = hipMemsetAsync(partial, 0, (size_t)n_images * (3 * TFFT_STAT_MAX_BLOCKS + 1) * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    int step = (int)(((long long)PH * Ms) / 65536); if (step < 1) step = 1; if (step > 64) step = 64;       // ~65 k sampled values per plane
+    unsigned nbs = (unsigned)((PH + step - 1) / step);
+    { unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < 32u ? want : 32u; }
+    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed);
+    hipLaunchKernelGGL(k_select_guess, dim3(3 * n_images), dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
+    return hipGetLastError();
+}
+// (2) after the COLS_STAT step: the packed column 0, the candidates' level-2 histogram, the verified select
+hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s) {
+    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    const dim3 gs(3 * n_images);
+    hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0, PH, st, cand, cand_stride);
+    unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
+    if (nbh < 16) nbh = 16;
+    if (nbh > 256) nbh = 256;
+    hipLaunchKernelGGL(k_hist_cand2, dim3(nbh, 3, n_images), dim3(256), 1024 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    return hipGetLastError();
+}
+// (3) the planes the fast path could not settle (their spectrum has been produced by the gated plain step in between), the capacity
+hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st, float* med_out, const CapParams* cap,
+                              unsigned* partial, float* amb, unsigned long long* usable, hipStream_t s) {
+    const int M = PW >> 1;
+    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
+    const unsigned fin_lds = (4096 + 256 + 16) * sizeof(unsigned) + 4 * sizeof(unsigned long long);
+    hipLaunchKernelGGL(k_median_fallback, dim3(3 * n_images), dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, 0);
+    if (cap) {
+        unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;
+        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)TFFT_STAT_MAX_BLOCKS, amb, usable, flag,
+                           spec, *cap, 1);
     }
     return hipGetLastError();
 }

@@ -622,7 +622,7 @@ def _ctx_with_env(env, *a, **kw):
                 os.environ[k] = v
 
 
-def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, center=False, sort=True, lsb_frac=0.01, with_oracle=True):
+def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, center=False, sort=True, lsb_frac=0.01, with_oracle=True, tile_stats=True):
     """Batched embedding as the default pipeline runs it -- stego = cover + IFFT(F' - F), the first inverse column step building its
     tiles from the bucketed bins (S:712-732 per bin, S:1099-1102 by linearity) -- against (a) the fp64 reference's stego image,
     (b) the write-F'-then-invert pipeline (TFFT_EMBED_DELTA=0), and (c) the reference's reading of OUR stego image."""
@@ -654,6 +654,18 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
             raw = bufs.get(rb).copy()
         ctx.close()
     (sd, ud), (s0, u0) = out["1"], out["0"]
+    # TFFT_STATS_TILE=1 (optional, off by default): the statistics of the delta pipeline inside the last forward column step, no stored
+    # spectrum: same capacities, same stego bytes; and with every bracket moved off the median (test hook) its fast path fails and the
+    # gated fallback must return them too
+    for env in (({"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"}) if tile_stats else ()):
+        ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
+        if idx is not None:
+            ctx.set_bit_index(idx)
+        ob, po = bufs.put(np.zeros_like(covers)); ub, pu = bufs.put(np.zeros(nimg, np.uint64))
+        ctx.embed_batch_dev(nimg, pc, w, h, pb, pbits, n_bits, po, center=center, rmax=rmax, usable_ptr=pu)
+        ctx.sync()
+        assert np.array_equal(bufs.get(ub), ud) and np.array_equal(bufs.get(ob), sd), ("tile statistics (optional path)", env)
+        ctx.close()
     assert np.array_equal(ud, u0)
     assert np.array_equal(bufs.get(cb), covers), "the cover buffer is read, never written"
     stats = []

@@ -41,11 +41,11 @@ for stage, pat in {
     "rows_fwd": r"k_rowcol_fwd<|k_rows_fwd<",
     "rows_inv": r"k_colrow_inv<|k_rows_inv<",
     "cols_fwd_a": r"k_fft_cols<\d+, 1, 0, false, true>",                 # first forward column step (output twiddles)
-    "cols_fwd_b": r"k_fft_cols<\d+, 1, 0, (true|false), false>",         # final forward column step
+    "cols_fwd_b": r"k_fft_cols<\d+, 1, [04], (true|false), false>",      # final forward column step (mode 4: it also writes the listed bins' values, delta embedding)
     "cols_fwd_read": r"k_fft_cols<\d+, 1, [12], ",                       # the same step as extraction runs it
-    "cols_inv_a": r"k_fft_cols<\d+, -1, 0, (true|false), true>",         # first inverse column step
+    "cols_inv_a": r"k_fft_cols<\d+, -1, [03], (true|false), true>",      # first inverse column step (mode 3: tiles built from the bin lists, delta embedding)
     "cols_inv_b": r"k_fft_cols<\d+, -1, 0, false, false>",               # last inverse column step (three-pass plans)
-    "embed": r"k_embed$", "read": r"k_read$", "capacity": r"k_capacity<",
+    "embed": r"k_gather_bits$|k_embed$", "read": r"k_read$", "capacity": r"k_capacity<",
 }.items():
     if stage in stages:
         continue
