@@ -87,6 +87,11 @@ struct tfft_ctx {
     int tile_read = 1;                    // TFFT_TILE_READ=0: row-limited spectrum + k_read always; 1: tile read for chunks of >= 8 images; 3: always; 2: always, with the global-atomic bucket build
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // delta embedding leaves the statistics off the critical path (nothing downstream reads the medians): they run on a stream of
+    // their own beside the inverse transform -- a read-only pass next to a write-only one (TFFT_STATS_ASYNC=0: in line)
+    hipStream_t stream_stats[2] = {nullptr, nullptr};
+    hipEvent_t ev_stats_fork[2] = {nullptr, nullptr}, ev_stats_join[2] = {nullptr, nullptr};
+    int stats_async = 1;
     int n_streams = 1;
     int n_cus = 0, collect_resident = 0;  // grid sizing of the full median pass: fill every CU to the same depth
     const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
@@ -532,6 +537,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_FUSE_LIVE")) c->fuse_live = atoi(e);
     if (const char* e = getenv("TFFT_EMBED_DELTA")) c->embed_delta = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_ASYNC")) c->stats_async = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_SKEW")) c->stats_tile_skew = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
@@ -593,6 +599,11 @@ int tfft_destroy(tfft_ctx* c) {
     for (int i = 0; i < 4; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_comp[i]) (void)hipEventDestroy(c->ev_comp[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int i = 0; i < 2; i++) {
+        if (c->stream_stats[i]) (void)hipStreamDestroy(c->stream_stats[i]);
+        if (c->ev_stats_fork[i]) (void)hipEventDestroy(c->ev_stats_fork[i]);
+        if (c->ev_stats_join[i]) (void)hipEventDestroy(c->ev_stats_join[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
@@ -1004,22 +1015,38 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
     rc = enqueue_forward(c, s0, g, rgb_in, st);
     c->fwd_emit = nullptr;
     if (rc) return rc;
+    hipStream_t sst = st;       // the stream the statistics run on
+    const bool async = delta && usable && c->stats_async;
+    if (async) {
+        if (!c->stream_stats[which]) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_stats[which], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_fork[which], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_join[which], hipEventDisableTiming));
+        }
+        sst = c->stream_stats[which];
+        HIPCHK(c, hipEventRecord(c->ev_stats_fork[which], st));
+        HIPCHK(c, hipStreamWaitEvent(sst, c->ev_stats_fork[which], 0));
+    }
     if (usable) {      // S:922-923, S:998-1012 on the device, no host round trip: capacity is counted inside the median's full pass
         CapParams p = cap_params(c, s, rmin, rmax);
         p.magmin = magmin;
         if (c->stats_fused && p.bw > 0) {
-            rc = enqueue_medians(c, s0, g, st, &p, usable);
+            rc = enqueue_medians(c, s0, g, sst, &p, usable);
             if (rc) return rc;
         } else {
-            rc = enqueue_medians(c, s0, g, st);
+            rc = enqueue_medians(c, s0, g, sst);
             if (rc) return rc;
-            HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), usable, st));
+            HIPCHK(c, launch_capacity(c->spec(s0), p, g, c->med + 3 * s0, c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), usable, sst));
         }
     }
     if (delta) {
         c->inv_embed = &em; c->inv_cover = rgb_in;
         rc = enqueue_inverse(c, s0, g, rgb_out, st);
         c->inv_embed = nullptr; c->inv_cover = nullptr;
+        if (async) {            // whoever waits for the context's stream has the capacities too
+            HIPCHK(c, hipEventRecord(c->ev_stats_join[which], sst));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_stats_join[which], 0));
+        }
         return rc;
     }
     HIPCHK(c, launch_embed(c->spec(s0), bins, bits, nullptr, ep, g, c->err, st));
