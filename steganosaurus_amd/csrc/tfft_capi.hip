@@ -92,6 +92,7 @@ struct tfft_ctx {
     hipStream_t stream_stats[2] = {nullptr, nullptr};
     hipEvent_t ev_stats_fork[2] = {nullptr, nullptr}, ev_stats_join[2] = {nullptr, nullptr};
     int stats_async = 1;
+    int stats_m2 = 1;                     // batched delta embeds store |F|^2 (half the bytes) for the statistics instead of the spectrum nobody else reads (TFFT_STATS_M2=0)
     int n_streams = 1;
     int n_cus = 0, collect_resident = 0;  // grid sizing of the full median pass: fill every CU to the same depth
     const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
@@ -214,7 +215,7 @@ void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw de
 
 static void copy_embed_fields(ColParams& cp, const ColParams& e) {
     cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off;
-    cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1;
+    cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1; cp.em_m2 = e.em_m2;
     cp.st_sel = e.st_sel; cp.st_cand = e.st_cand; cp.st_cand_stride = e.st_cand_stride; cp.st_partial = e.st_partial; cp.st_amb = e.st_amb;
     cp.st_col0 = e.st_col0; cp.st_slo = e.st_slo; cp.st_shi = e.st_shi; cp.st_cap = e.st_cap; cp.st_PW = e.st_PW;
 }
@@ -403,15 +404,22 @@ CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax)
 }
 
 // medians of slots [s0, s0+n); cap != nullptr: also their capacities (S:998-1008 with thr = magmin * median) -> usable[0..n)
-int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap = nullptr, unsigned long long* usable = nullptr) {
+// m2: the slots hold |F|^2 planes + packed columns 0 (stats_m2_applies) instead of the spectrum
+int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap = nullptr, unsigned long long* usable = nullptr, bool m2 = false) {
     const Slot& s = c->slots[s0];
     // the batch capacity keeps its partial counts and flags in ONE region per call: slots [s0, s0+n) use the start of the pool's
     // share of the compute stream (s0 is 0 or the second half of a two-stream chunk: shares do not overlap for n <= n_slots - s0)
     unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
                              c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st,
-                             cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable, c->stats_compact));
+                             cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable, c->stats_compact,
+                             m2 ? c->col0_pool + (size_t)s0 * 3 * s.PH : nullptr, c->stats_tile_skew));
     return TFFT_OK;
+}
+// the batched delta embeds with capacity: may the last forward step store |F|^2 instead of the spectrum?
+static bool stats_m2_applies(const tfft_ctx* c, const Slot& s, const CapParams& p) {
+    return c->stats_m2 && c->stats_fused && c->stats_compact && !c->median_force_fallback && p.bw > 0 &&
+           (unsigned long long)s.PH * s.PWi <= (1ull << 24);
 }
 
 int ensure_stage(tfft_ctx* c, uint64_t n) {
@@ -538,7 +546,9 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_EMBED_DELTA")) c->embed_delta = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
     if (const char* e = getenv("TFFT_STATS_ASYNC")) c->stats_async = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_M2")) c->stats_m2 = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_SKEW")) c->stats_tile_skew = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_SKEW")) c->stats_tile_skew = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
@@ -992,7 +1002,12 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         auto& tb = c->tb[which];
         em.rd_bins = tb.ent; em.rd_off = tb.off; em.em_fl = tb.fl + (size_t)s0 * n_bits; em.em_pb = tb.pb + (size_t)s0 * n_bits;
         em.em_n = n_bits; em.em_cos = ep.cos_a; em.em_sin = ep.sin_a;
-        // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way)
+        if (usable) {
+            CapParams p0 = cap_params(c, s, rmin, rmax);
+            if (stats_m2_applies(c, s, p0)) { em.em_m2 = 1; em.st_col0 = c->col0_pool + (size_t)s0 * 3 * s.PH; }
+        }
+        // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way).  (On the side stream
+        // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
         c->fwd_emit = &em;
     }
@@ -1003,6 +1018,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         CapParams p = cap_params(c, s, rmin, rmax);
         p.magmin = magmin;
         if (p.bw > 0 && pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24)) {
+            em.em_m2 = 0;
             rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable);
             c->fwd_emit = nullptr;
             if (rc) return rc;
@@ -1031,7 +1047,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         CapParams p = cap_params(c, s, rmin, rmax);
         p.magmin = magmin;
         if (c->stats_fused && p.bw > 0) {
-            rc = enqueue_medians(c, s0, g, sst, &p, usable);
+            rc = enqueue_medians(c, s0, g, sst, &p, usable, em.em_m2 != 0);
             if (rc) return rc;
         } else {
             rc = enqueue_medians(c, s0, g, sst);
@@ -1481,6 +1497,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     tcap.magmin = 0.01;
     const bool tile = delta && bits_dev && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback && tcap.bw > 0 &&
                       pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
+    const bool m2 = delta && bits_dev && !tile && stats_m2_applies(c, s, tcap);      // the spectrum is stored as |F|^2 + column 0 (see embed_chunk)
     if (tile && stage == MEDIANS) launches = 11;       // sample step, histogram, guess (+ memset), 5 select kernels, gated step, fallback, settle
 
     if (n_launches) *n_launches = launches;
@@ -1512,6 +1529,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
         em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
         em.em_cos = ep0.cos_a; em.em_sin = ep0.sin_a;
+        if (m2) { em.em_m2 = 1; em.st_col0 = c->col0_pool; }
     }
     if (tile && (stage == final_fwd || stage == MEDIANS)) {
         float ms_all = 0.f, ms_c = 0.f;
@@ -1578,7 +1596,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
                 if (c->stats_fused) {
                     CapParams p = cap_params(c, s, 0.05, 0.45);
                     p.magmin = 0.01;
-                    rc = enqueue_medians(c, 0, n_images, c->stream, &p, c->usable);
+                    rc = enqueue_medians(c, 0, n_images, c->stream, &p, c->usable, m2);
                 } else rc = enqueue_medians(c, 0, n_images, c->stream);
                 break;
             case CAPACITY: {

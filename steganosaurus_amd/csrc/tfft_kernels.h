@@ -44,6 +44,8 @@ struct ColParams {
     // in bucket order; the FIRST inverse step (COLS_EMBED) starts every tile as zeros and puts F' - F at those bins, F taken from
     // em_fl (S:712-732 with a fixed alpha)
     float2* em_fl;                   // em_n values per image, indexed like rd_bins
+    int em_m2;                       // COLS_EMIT: store |F|^2 (float, `out` reinterpreted, same byte offset per image) instead of the complex
+                                     // spectrum, the packed column 0 to st_col0: all the statistics read (launch_medians col0_m2)
     const uint8_t* em_pb;            // COLS_EMBED: em_n stream bits per image in the same order (k_gather_bits; 2 = not written)
     uint64_t em_n;                   // list stride between images (the length of the bin list)
     float em_cos, em_sin;
@@ -171,7 +173,7 @@ hipError_t launch_read(const float2* spec, const tfft_bin* bins, const float* ji
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident, hipStream_t s,
                           const CapParams* cap = nullptr, unsigned* partial = nullptr, float* amb = nullptr, unsigned long long* usable = nullptr,
-                          int compact = 1);
+                          int compact = 1, const float2* col0_m2 = nullptr, int skew = 0);
 int collect_bracket_resident_blocks();
 hipError_t launch_capacity(const float2* spec, const CapParams& P, int n_images, const float* med_dev,
                            unsigned* partial, unsigned long long* usable, hipStream_t s, const unsigned* only_flagged = nullptr);

@@ -975,7 +975,9 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // NE entries per thread travel in registers; a longer bucket fetches the rest in place.
     // Every fetch is UNCONDITIONAL at a clamped, always valid address, and nothing looks at a fetched word before the stage that uses
     // it: a load inside a predicated block is followed by its own s_waitcnt vmcnt(0) (32 serialised round trips were seen).
-    constexpr int NE = 2;
+    // entries per thread that travel in registers.  4K: ~1650 entries per bucket and 512 threads, 1080p: ~240 and 256.  Four help the
+    // forward step at 4K (0.78 -> 0.75 ms per 8-image launch) and cost the inverse step there (0.55 -> 0.60): it keeps two
+    constexpr int NE = (LOGL >= 9 && MODE != COLS_EMBED) ? 4 : 2;
     struct EmEntry { TileBin tb; float2 f; unsigned bit, live; };   // bucket entry, the stored value of its bin (conjugate of the bin when
                                                                     // tb.conj) and its stream bit (2: beyond the end of the stream)
     EmEntry enC[NE], enN[NE];
@@ -1175,7 +1177,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     float2 v = u[m];
                     if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
-                    dst[(size_t)row * oM] = v;
+                    if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes
+                        reinterpret_cast<float*>(out + (size_t)img * P.img_stride)[(size_t)plane * P.plane_stride + (size_t)row * P.M + col] = fmaf(v.x, v.x, v.y * v.y);
+                        if (col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
+                    } else dst[(size_t)row * oM] = v;
                 }
             }
         }
@@ -1548,28 +1553,41 @@ __device__ __forceinline__ SelectState* sel_of(SelectState* st) { return st + (s
 // a given rank is the same and the median is the square root of the selected value -- one sqrt per plane
 // instead of one per bin.
 __device__ __forceinline__ float mag2_of(float2 v) { return fmaf(v.x, v.x, v.y * v.y); }
+// col0 != nullptr: `pl` is a plane of |F|^2 (float, the batched delta embeds store nothing else: ColParams::em_m2) and the packed
+// column 0, which cannot be unpacked from magnitudes, lives in col0[PH]
 template <class F>
-__device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f, bool col0_packed = true) {
+__device__ __forceinline__ void for_each_mag(const float2* __restrict__ pl, int PH, int M, int y, int x, F&& f, bool col0_packed = true,
+                                             const float2* __restrict__ col0 = nullptr) {
     if (x == 0 && col0_packed) {
-        float2 f0, fm; unpack_col0(pl, y, PH, M, f0, fm);
+        float2 f0, fm;
+        if (col0) unpack_col0(col0, y, PH, 1, f0, fm);
+        else unpack_col0(pl, y, PH, M, f0, fm);
         f(__float_as_uint(mag2_of(f0)), 1u); f(__float_as_uint(mag2_of(fm)), 1u);
+    } else if (col0) {
+        f(__float_as_uint(reinterpret_cast<const float*>(pl)[(size_t)y * M + x]), 2u);
     } else {
         f(__float_as_uint(mag2_of(pl[(size_t)y * M + x])), 2u);
     }
 }
+// plane `plane` of image `img`: complex planes are img_stride float2 apart; the |F|^2 planes sit at the same BYTE offsets per image
+__device__ __forceinline__ const float2* stat_plane(const float2* spec, size_t img_stride, int img, int plane, int PH, int M, bool m2) {
+    return m2 ? reinterpret_cast<const float2*>(reinterpret_cast<const float*>(spec + (size_t)img * img_stride) + (size_t)plane * PH * M)
+              : spec + (size_t)img * img_stride + (size_t)plane * PH * M;
+}
 
 // histogram of rows y0, y0+row_step, ... ; guarded != 0: fallback role, skip when the fast path succeeded
 __global__ void k_hist_spec(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
-                            SelectState* __restrict__ st, int row_step, int guarded, int col0_packed = 1) {
+                            SelectState* __restrict__ st, int row_step, int guarded, int col0_packed = 1, const float2* __restrict__ col0 = nullptr) {
     SelectState* s = sel_of(st);
     if (guarded && s->done) return;
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);      // 4096 counters
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
+    const float2* pl = stat_plane(spec, img_stride, blockIdx.z, blockIdx.y, PH, M, col0 != nullptr);
+    const float2* c0 = col0 ? col0 + ((size_t)blockIdx.z * 3 + blockIdx.y) * PH : nullptr;
     for (int y = blockIdx.x * row_step; y < PH; y += gridDim.x * row_step)
         for (int x = threadIdx.x; x < M; x += blockDim.x)
-            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); }, col0_packed != 0);
+            for_each_mag(pl, PH, M, y, x, [&](unsigned b, unsigned w) { atomicAdd(&hist[b >> 19], w); }, col0_packed != 0, c0);
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += blockDim.x)
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
@@ -1652,6 +1670,18 @@ struct BracketSeg {
     float4 v[8];                        // columns x0 + 2*(q*64 + lane) and the one after it
     float2 partner;                     // lane 0 of segment 0: row PH-y of the packed column 0
 };
+// |F|^2 planes (M2IN): the two values of a lane and q land in .x and .z, the packed column 0 is not in the plane (k_col0_stats)
+__device__ __forceinline__ void bracket_load_m2(BracketSeg& r, const float* __restrict__ pl, int M, int y, int x0, int lane) {
+    const float* row = pl + (size_t)y * M;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int x = x0 + 2 * (q * 64 + lane);
+        if (x + 1 < M) { const float2 a = *reinterpret_cast<const float2*>(row + x); r.v[q] = make_float4(a.x, 0.f, a.y, 0.f); }
+        else if (x < M) r.v[q] = make_float4(row[x], 0.f, 0.f, 0.f);
+        else r.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    r.partner = make_float2(0.f, 0.f);
+}
 __device__ __forceinline__ void bracket_load(BracketSeg& r, const float2* __restrict__ pl, int PH, int M, int y, int x0, int lane) {
     const float2* row = pl + (size_t)y * M;
 #pragma unroll
@@ -1682,7 +1712,7 @@ __device__ __forceinline__ void annulus_row(unsigned long long yy, unsigned long
 // and its mirror ((PH-y)%PH, PW-x) of equal magnitude; each counts when it is off the axes and inside the annulus.  Per row
 // that is two column intervals (wave uniform), per element two range tests and a compare against the bracket of the
 // threshold (SelectState::t2_lo/t2_hi); the few values inside that bracket are parked for k_capacity_settle.
-template <bool CAP>
+template <bool CAP, bool M2IN = false>
 __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restrict__ spec, int PH, int M, size_t img_stride,
                                   SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride,
                                   unsigned long long s_lo, unsigned long long s_hi, int PWfull, unsigned* __restrict__ partial,
@@ -1693,7 +1723,8 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
     SelectState* s = sel_of(st);
     const unsigned lo = s->lo, hi = s->hi, base_bits = lo << 19;
     unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
-    const float2* pl = spec + (size_t)blockIdx.z * img_stride + (size_t)blockIdx.y * PH * M;
+    const float2* pl = stat_plane(spec, img_stride, blockIdx.z, blockIdx.y, PH, M, M2IN);
+    const float* plm = reinterpret_cast<const float*>(pl);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned* buf = wbuf + wave * 512; unsigned* cnt = wcnt + wave * 2;
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
@@ -1754,16 +1785,16 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
     int y = blockIdx.x * 4 + wave, x0 = 0;
     bool have = y < PH;
     BracketSeg cur;
-    if (have) bracket_load(cur, pl, PH, M, y, x0, lane);
+    if (have) { if (M2IN) bracket_load_m2(cur, plm, M, y, x0, lane); else bracket_load(cur, pl, PH, M, y, x0, lane); }
     while (have) {
         int ny = y, nx0 = x0 + 1024;
         if (nx0 >= M) { nx0 = 0; ny = y + ystep; }
         const bool nhave = ny < PH;
         BracketSeg nxt;
-        if (nhave) bracket_load(nxt, pl, PH, M, ny, nx0, lane);
+        if (nhave) { if (M2IN) bracket_load_m2(nxt, plm, M, ny, nx0, lane); else bracket_load(nxt, pl, PH, M, ny, nx0, lane); }
         if (CAP && x0 == 0) cap_row(y);
         const bool cap_live = CAP && (ca1 <= cb1 || ca2 <= cb2);      // wave uniform
-        if (x0 == 0) {                  // packed column 0 (lane 0): F[y][0] and F[y][M], once each (unpack_col0)
+        if (!M2IN && x0 == 0) {         // packed column 0 (lane 0): F[y][0] and F[y][M], once each (unpack_col0); M2IN: k_col0_stats
             const float2 a = make_float2(cur.v[0].x, cur.v[0].y), b2 = cur.partner;
             const float2 f0 = make_float2(0.5f * (a.x + b2.x), 0.5f * (a.y - b2.y));
             const float2 fm = make_float2(0.5f * (a.y + b2.y), -0.5f * (a.x - b2.x));
@@ -1773,7 +1804,7 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int x = x0 + 2 * (q * 64 + lane);
-            const float ma2 = mag2_of(make_float2(cur.v[q].x, cur.v[q].y)), mb2 = mag2_of(make_float2(cur.v[q].z, cur.v[q].w));
+            const float ma2 = M2IN ? cur.v[q].x : mag2_of(make_float2(cur.v[q].x, cur.v[q].y)), mb2 = M2IN ? cur.v[q].z : mag2_of(make_float2(cur.v[q].z, cur.v[q].w));
             classify(x != 0 && x < M, __float_as_uint(ma2), 2u);
             classify(x + 1 < M, __float_as_uint(mb2), 2u);
             if (cap_live) { cap_elem(x, ma2); cap_elem(x + 1, mb2); }          // x = 0 and x >= M fall outside [1, M-1] by themselves
@@ -1818,7 +1849,7 @@ __global__ void __launch_bounds__(256) k_collect_bracket(const float2* __restric
 //   recount = 1: this block recounts it itself over the annulus box (rare and slow: one block per image).
 __global__ void k_capacity_settle(const SelectState* __restrict__ st, const float* __restrict__ med, double magmin, const unsigned* __restrict__ partial,
                                   int nb, const float* __restrict__ amb, unsigned long long* __restrict__ usable, unsigned* __restrict__ flag,
-                                  const float2* __restrict__ spec, CapParams P, int recount) {
+                                  const float2* __restrict__ spec, CapParams P, int recount, int m2in = 0) {
     unsigned long long* c = reinterpret_cast<unsigned long long*>(tfft_smem);   // [3] + bad
     unsigned* bad = reinterpret_cast<unsigned*>(c + 3);
     const int img = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1843,7 +1874,8 @@ __global__ void k_capacity_settle(const SelectState* __restrict__ st, const floa
         const int M = P.PWi >> 1;
         for (int q = 0; q < 3; q++) {
             const float tq = mag2_threshold(magmin * (double)med[img * 3 + q]);
-            const float2* pl = spec + (size_t)img * P.img_stride + (size_t)q * P.PH * M;
+            const float2* pl = stat_plane(spec, P.img_stride, img, q, P.PH, M, m2in != 0);
+            const float* plm = reinterpret_cast<const float*>(pl);
             unsigned long long mine = 0;
             for (int y = 1; y < P.bh; y++) {
                 if (2 * y == P.PH) continue;
@@ -1854,8 +1886,10 @@ __global__ void k_capacity_settle(const SelectState* __restrict__ st, const floa
                     if (2 * x == P.PW) continue;
                     const unsigned long long r2 = yy + (unsigned long long)x * (unsigned long long)x;
                     if (r2 < P.s_lo || r2 > P.s_hi) continue;
-                    const float2 v = x < M ? row[x] : mrow[P.PW - x];
-                    if (!(mag2_of(v) < tq)) mine++;
+                    float m2;
+                    if (m2in) m2 = x < M ? plm[(size_t)y * M + x] : plm[(size_t)((P.PH - y) & (P.PH - 1)) * M + (P.PW - x)];
+                    else m2 = mag2_of(x < M ? row[x] : mrow[P.PW - x]);
+                    if (!(m2 < tq)) mine++;
                 }
             }
             if (mine) atomicAdd(&c[q], mine);
@@ -1927,7 +1961,8 @@ __global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __rest
 // statistics inside the last forward column step (COLS_STAT): what that kernel leaves to do.
 // (a) the packed column 0: F[y][0] and F[y][M] (unpack_col0), one value of weight 1 each, classified like k_collect_bracket does;
 //     neither column belongs to the annulus count (x = 0 and 2x = PW are excluded, S:698-700)
-__global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride) {
+__global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride,
+                             int with_hist) {
     SelectState* s = st + (size_t)blockIdx.z * 3 + blockIdx.y;
     const float2* cz = col0 + ((size_t)blockIdx.z * 3 + blockIdx.y) * PH;
     unsigned* out = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
@@ -1941,7 +1976,11 @@ __global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectStat
         for (int i = 0; i < 2; i++) {
             const unsigned bk = v[i] >> 19;
             if (bk < lo) below++;
-            else if (bk - lo <= span) out[atomicAdd(&s->n_cand, 1u)] = v[i] - base_bits;      // weight 1: bit 31 clear
+            else if (bk - lo <= span) {
+                const unsigned rel = v[i] - base_bits;
+                out[atomicAdd(&s->n_cand, 1u)] = rel;                                           // weight 1: bit 31 clear
+                if (with_hist) atomicAdd(&s->hist[rel >> 11], 1u);                              // the level-2 histogram k_collect_bracket keeps
+            }
         }
     }
     if (below) atomicAdd(&s->below, (unsigned long long)below);
@@ -2026,13 +2065,14 @@ __global__ void __launch_bounds__(1024) k_select_finish(SelectState* __restrict_
 // The plain three-level radix select (4096 / 1024 / 512 buckets of the float's bits, as k_select<1..3>) by ONE block per plane:
 // three passes of that block over its plane.  Runs only where the fast path did not verify (or when forced): slow and rare.
 __global__ void __launch_bounds__(1024) k_median_fallback(const float2* __restrict__ spec, int PH, int M, size_t img_stride, SelectState* __restrict__ st,
-                                                          float* __restrict__ med_out, unsigned long long rank, int force) {
+                                                          float* __restrict__ med_out, unsigned long long rank, int force, const float2* __restrict__ col0 = nullptr) {
     SelectState* s = st + blockIdx.x;
     if (!force && s->done) return;
     unsigned* h = reinterpret_cast<unsigned*>(tfft_smem); unsigned* p1 = h + 4096; unsigned* p2 = p1 + 256;
     unsigned long long* res = reinterpret_cast<unsigned long long*>(p2 + 16);
     const int img = blockIdx.x / 3, plane = blockIdx.x - 3 * img, t = threadIdx.x;
-    const float2* pl = spec + (size_t)img * img_stride + (size_t)plane * PH * M;
+    const float2* pl = stat_plane(spec, img_stride, img, plane, PH, M, col0 != nullptr);
+    const float2* c0 = col0 ? col0 + (size_t)blockIdx.x * PH : nullptr;
     const size_t n = (size_t)PH * M;
     unsigned prefix = 0;
     for (int level = 1; level <= 3; level++) {
@@ -2044,7 +2084,7 @@ __global__ void __launch_bounds__(1024) k_median_fallback(const float2* __restri
                 if (level == 1) atomicAdd(&h[b >> 19], w);
                 else if (level == 2) { if ((b >> 19) == prefix) atomicAdd(&h[(b >> 9) & 1023u], w); }
                 else { if ((b >> 9) == prefix) atomicAdd(&h[b & 511u], w); }
-            });
+            }, true, c0);
         }
         int b; unsigned long long before;
         find_bucket_blk(h, p1, p2, res, rank, level == 1 ? 4096 : level == 2 ? 1024 : 512, b, before);
@@ -2524,6 +2564,7 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
     if (P.em_on && !P.em_fl) return hipErrorInvalidValue;
+    if (P.em_m2 && sign > 0 && (!P.em_on || !P.st_col0)) return hipErrorInvalidValue;      // (the inverse step ignores it)
     if (P.st_sel && (!P.em_on || sign < 0 || logl > 9 || !P.st_cand || !P.st_col0 || (P.st_cap && (!P.st_partial || !P.st_amb)))) return hipErrorInvalidValue;
     if ((P.tile_step > 1 || P.gate) && (sign < 0 || P.rd_bins || P.last_row_dev || P.tw_out)) return hipErrorInvalidValue;      // plain final forward step only
 #define G(n, MODE)                                                                      \
@@ -2604,9 +2645,18 @@ static unsigned stat_blocks(int rows, int n_images) {
     return (unsigned)nb;
 }
 
+// test hook (TFFT_STATS_TILE_SKEW): move every bracket by `skew` level-1 buckets, so that the fast path fails and the gated fallback runs
+__global__ void k_skew_bracket(SelectState* __restrict__ st, int skew) {
+    SelectState* s = st + blockIdx.x;
+    if (threadIdx.x == 0) { s->lo = (unsigned)imax(0, imin(4093, (int)s->lo + skew)); s->hi = s->lo + 2; }
+}
 hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st,
                           unsigned* cand, size_t cand_stride, float* med_out, int force_fallback, int fill_cus, int fill_resident,
-                          hipStream_t s, const CapParams* cap, unsigned* partial, float* amb, unsigned long long* usable, int compact) {
+                          hipStream_t s, const CapParams* cap, unsigned* partial, float* amb, unsigned long long* usable, int compact,
+                          const float2* col0_m2, int skew) {
+    // col0_m2 != nullptr: `spec` holds |F|^2 planes (float) and col0_m2 the packed columns 0 (the batched delta embeds store nothing
+    // else); only the compact pipeline reads that form
+    if (col0_m2 && (!compact || force_fallback || (unsigned long long)PH * PW > (1ull << 24))) return hipErrorInvalidValue;
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;     // mags.size()/2 (S:407)
     const unsigned nb = stat_blocks(PH, n_images);
@@ -2631,8 +2681,9 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         // full passes get: 4 sampled rows per block, at most 32 blocks per plane (their ~150 non-zero buckets each go to global atomics)
         unsigned nbs = (unsigned)((PH + step - 1) / step);
         { unsigned cap = nb > 32u ? nb : 32u; unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < cap ? want : cap; }
-        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0, 1);
+        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, step, 0, 1, col0_m2);
         hipLaunchKernelGGL(k_select_guess, gs, dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
+        if (skew) hipLaunchKernelGGL(k_skew_bracket, gs, dim3(64), 0, s, st, skew);      // test hook: the fast path fails, the fallbacks run
         // The whole grid of the full pass is resident at once, so its run time is that of the fullest CU:
         // 1056 workgroups on 256 CUs meant 4 on most and 5 on some, i.e. 5/1056 of the work on the critical
         // CU.  Fill every CU to the same depth instead: the largest grid that fits the residency limit.
@@ -2644,7 +2695,15 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         if (nbc > TFFT_STAT_MAX_BLOCKS) nbc = TFFT_STAT_MAX_BLOCKS;
         if (nbc < 1) nbc = 1;
         nbc_used = nbc;
-        if (cap)
+        if (col0_m2) {
+            if (cap)
+                hipLaunchKernelGGL((k_collect_bracket<true, true>), dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
+                                   img_stride, st, cand, cand_stride, cap->s_lo, cap->s_hi, cap->PW, partial, amb);
+            else
+                hipLaunchKernelGGL((k_collect_bracket<false, true>), dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
+                                   img_stride, st, cand, cand_stride, 0ull, 0ull, 0, nullptr, nullptr);
+            hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0_m2, PH, st, cand, cand_stride, 1);
+        } else if (cap)
             hipLaunchKernelGGL(k_collect_bracket<true>, dim3(nbc, 3, n_images), dim3(256), (1024 + 4 * 512 + 8) * sizeof(unsigned), s, spec, PH, M,
                                img_stride, st, cand, cand_stride, cap->s_lo, cap->s_hi, cap->PW, partial, amb);
         else
@@ -2664,10 +2723,10 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     }
     if (compact) {
         // fallback: one block per plane, returns at once where the fast path verified
-        hipLaunchKernelGGL(k_median_fallback, gs, dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, force_fallback ? 1 : 0);
+        hipLaunchKernelGGL(k_median_fallback, gs, dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, force_fallback ? 1 : 0, col0_m2);
     } else {
         // fallback: plain three-level select; every block returns immediately when the fast path verified
-        hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1, 1);
+        hipLaunchKernelGGL(k_hist_spec, g3, dim3(256), 4096 * sizeof(unsigned), s, spec, PH, M, img_stride, st, 1, 1, 1, (const float2*)nullptr);
         hipLaunchKernelGGL(k_select<1>, gs, dim3(256), sel_lds, s, st, med_out);
         hipLaunchKernelGGL(k_collect, g3, dim3(256), (1024 + 2048 + 2) * sizeof(unsigned), s, spec, PH, M, img_stride, st, cand, cand_stride);
         hipLaunchKernelGGL(k_select<2>, gs, dim3(256), sel_lds, s, st, med_out);
@@ -2679,7 +2738,7 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
         // overflowing park list, forced fallback) are recounted -- inside the settle block (compact) or by the plain kernel
         unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;      // n_images words behind the partial counts
         hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)nbc_used, amb, usable, flag,
-                           spec, *cap, compact ? 1 : 0);
+                           spec, *cap, compact ? 1 : 0, col0_m2 ? 1 : 0);
         if (!compact) {
             hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
             if (e != hipSuccess) return e;
@@ -2688,11 +2747,6 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
     return hipGetLastError();
 }
 
-// test hook (TFFT_STATS_TILE_SKEW): move every bracket by `skew` level-1 buckets, so that the fast path fails and the gated fallback runs
-__global__ void k_skew_bracket(SelectState* __restrict__ st, int skew) {
-    SelectState* s = st + blockIdx.x;
-    if (threadIdx.x == 0) { s->lo = (unsigned)imax(0, imin(4093, (int)s->lo + skew)); s->hi = s->lo + 2; }
-}
 hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s) {
     hipLaunchKernelGGL(k_skew_bracket, dim3(3 * n_images), dim3(64), 0, s, st, skew);
     return hipGetLastError();
@@ -2708,7 +2762,7 @@ hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t 
     int step = (int)(((long long)PH * Ms) / 65536); if (step < 1) step = 1; if (step > 64) step = 64;       // ~65 k sampled values per plane
     unsigned nbs = (unsigned)((PH + step - 1) / step);
     { unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < 32u ? want : 32u; }
-    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed);
+    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed, (const float2*)nullptr);
     hipLaunchKernelGGL(k_select_guess, dim3(3 * n_images), dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
     return hipGetLastError();
 }
@@ -2716,7 +2770,7 @@ hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t 
 hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s) {
     const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
     const dim3 gs(3 * n_images);
-    hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0, PH, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0, PH, st, cand, cand_stride, 0);
     unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
     if (nbh < 16) nbh = 16;
     if (nbh > 256) nbh = 256;
@@ -2732,11 +2786,11 @@ hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_str
     const int M = PW >> 1;
     const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
     const unsigned fin_lds = (4096 + 256 + 16) * sizeof(unsigned) + 4 * sizeof(unsigned long long);
-    hipLaunchKernelGGL(k_median_fallback, dim3(3 * n_images), dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, 0);
+    hipLaunchKernelGGL(k_median_fallback, dim3(3 * n_images), dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, 0, (const float2*)nullptr);
     if (cap) {
         unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;
         hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)TFFT_STAT_MAX_BLOCKS, amb, usable, flag,
-                           spec, *cap, 1);
+                           spec, *cap, 1, 0);
     }
     return hipGetLastError();
 }

@@ -657,7 +657,18 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     # TFFT_STATS_TILE=1 (optional, off by default): the statistics of the delta pipeline inside the last forward column step, no stored
     # spectrum: same capacities, same stego bytes; and with every bracket moved off the median (test hook) its fast path fails and the
     # gated fallback must return them too
-    for env in (({"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"}) if tile_stats else ()):
+    # embedding in place (output buffer = cover buffer): the last kernel reads the cover's bytes it is about to overwrite
+    ctx = B.Context(w, h, slots=max(1, nimg - 1), lib=lib)
+    if idx is not None:
+        ctx.set_bit_index(idx)
+    ib, pi = bufs.put(covers)
+    ctx.embed_batch_dev(nimg, pi, w, h, pb, pbits, n_bits, pi, center=center, rmax=rmax)
+    ctx.sync()
+    assert np.array_equal(bufs.get(ib), sd), "in-place embedding"
+    ctx.close()
+    # TFFT_STATS_SKEW (test hook): every bracket moved off the median -- the fast path of the statistics fails and their fallbacks
+    # (on the |F|^2 planes the delta pipeline stores) must return the same capacities
+    for env in (({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"}) if tile_stats else ({"TFFT_STATS_SKEW": "5"},)):
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
             ctx.set_bit_index(idx)
