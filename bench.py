@@ -92,6 +92,8 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
         m2 = plan.get("m2", False)      # the spectrum is stored as |F|^2 (4 B per bin): all the statistics read, and nothing else reads it
         if stage == final_fwd and not (plan["fused"] and stage == "cols_fwd_a"):
             rd = (3 * plane_full) if two_step else 3 * plane_h
+            if plan.get("no_store", False):      # no capacity asked for (--no-stats): nobody reads the spectrum, nothing is stored
+                return rd + n_bits * (8 + 8)
             return rd + (cand if tile else (3 * plane_full // 2 if m2 else 3 * plane_full)) + n_bits * (8 + 8)
         if stage == "medians" and m2 and not tile:
             return int(3 * (plane_full // 2) * (1 + 1.0 / 16))
@@ -201,6 +203,7 @@ class Workload:
         PHp, PWp = next_pow2(H), max(2, next_pow2(W))
         self.plan["m2"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0 and int(os.environ.get("TFFT_STATS_TILE", "0")) == 0
                            and PHp * PWp <= (1 << 24))
+        self.plan["no_store"] = self.plan["delta"] and not stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0
         self.plan["tile_stats"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_TILE", "0")) != 0 and self.plan["log_n2"] <= 9
                                    and PHp * PWp <= (1 << 24))
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -1005,6 +1005,8 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         if (usable) {
             CapParams p0 = cap_params(c, s, rmin, rmax);
             if (stats_m2_applies(c, s, p0)) { em.em_m2 = 1; em.st_col0 = c->col0_pool + (size_t)s0 * 3 * s.PH; }
+        } else if (c->stats_m2) {      // no capacity asked for: nobody reads the spectrum, the last forward step stores nothing
+            em.em_m2 = 2; em.st_col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
         }
         // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way).  (On the side stream
         // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)

@@ -1177,9 +1177,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     float2 v = u[m];
                     if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
-                    if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes
-                        reinterpret_cast<float*>(out + (size_t)img * P.img_stride)[(size_t)plane * P.plane_stride + (size_t)row * P.M + col] = fmaf(v.x, v.x, v.y * v.y);
-                        if (col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
+                    if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
+                        if (P.em_m2 == 1) {                  // asked for, nothing at all)
+                            reinterpret_cast<float*>(out + (size_t)img * P.img_stride)[(size_t)plane * P.plane_stride + (size_t)row * P.M + col] = fmaf(v.x, v.x, v.y * v.y);
+                            if (col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
+                        }
                     } else dst[(size_t)row * oM] = v;
                 }
             }
