@@ -574,8 +574,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
-    c->mini_cols = M / 8 + 16;
-    if (!rc) rc = dev_alloc(c, (void**)&c->mini_pool, ns * 3 * (size_t)ph * c->mini_cols * sizeof(float2));
+    c->mini_cols = M / 8 + 16;          // (mini_pool itself is allocated by the first call that uses the optional tile statistics)
     if (!rc) rc = dev_alloc(c, (void**)&c->col0_pool, ns * 3 * (size_t)ph * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
@@ -925,13 +924,18 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     const int off = ntiles > step / 2 ? step / 2 : 0;
     const int Ms = 16 * ((ntiles - off + step - 1) / step);
     if ((size_t)Ms > c->mini_cols) return TFFT_E_STATE;
+    if (!c->mini_pool) {
+        (void)hipStreamSynchronize(c->stream);
+        invalidate_graphs(c);
+        if (dev_alloc(c, (void**)&c->mini_pool, (size_t)c->n_slots * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols * sizeof(float2))) return TFFT_E_NOMEM;
+    }
     int rc;
     for (int stage : {ROWS_FWD, COLS_FWD_A}) {
         if (stage == final_fwd || !(phases & 1)) break;
         rc = enqueue_fft_stage(c, s0, g, stage, rgb_in, nullptr, st);
         if (rc) return rc;
     }
-    float2* mini = c->mini_pool + (size_t)s0 * 3 * s.PH * c->mini_cols;
+    float2* mini = c->mini_pool + (size_t)s0 * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols;
     float2* col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
     SelectState* sel = c->sel + 3 * s0;
     unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
