@@ -312,7 +312,16 @@ def roofline_of(wl, stages, reps):
     d = stages[dom]
     traffic, src = load_traffic(wl.name, dom, d["images_per_launch"])
     sm_e, sm_x = survey_model_bytes(wl.W, wl.H, wl.n_bits)
-    return {"bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+    note = None
+    if wl.plan.get("m2") and dom in ("cols_fwd_a", "cols_fwd_b"):
+        # the step's own byte count shrank late in round 2 (it stores |F|^2, 4 B per bin, instead of the complex spectrum): say what
+        # the same launch time reads in the bytes it used to move, so that the drop in `frac` is not mistaken for a slower kernel
+        plan_c = dict(wl.plan, m2=False)
+        old_b = kernel_bytes(dom, wl.W, wl.H, wl.n_bins, wl.n_bins, plan_c) * d["images_per_launch"]
+        note = ("this step stores |F|^2 (4 B per bin, all the statistics read) instead of the complex spectrum since profiles/r2g: %d B per launch instead of "
+                "%d at the same speed; in the earlier byte count this launch time would read frac = %.3f.  The step is bound by its LDS exchanges and "
+                "dependent issue, not by HBM (DESIGN.md section 5)" % (d["bytes"], old_b, old_b / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    return {"bound": "hbm", "kernel": dom, "note": note, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
             "traffic": traffic,
             "traffic_source": (src or "profiles/traffic.json") + " -- rocprofv3 PMC of an earlier run of this same command, replayed, not measured in this run"
             if traffic is not None else None,
