@@ -668,14 +668,16 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     ctx.close()
     # TFFT_STATS_SKEW (test hook): every bracket moved off the median -- the fast path of the statistics fails and their fallbacks
     # (on the |F|^2 planes the delta pipeline stores) must return the same capacities
-    for env in (({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"}) if tile_stats else ({"TFFT_STATS_SKEW": "5"},)):
+    # ... TFFT_STATS_M2=0 / TFFT_STATS_ASYNC=0: the statistics on the complex spectrum, in line (the A/B forms of the default)
+    for env in (({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}, {"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"})
+                if tile_stats else ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"})):
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
             ctx.set_bit_index(idx)
         ob, po = bufs.put(np.zeros_like(covers)); ub, pu = bufs.put(np.zeros(nimg, np.uint64))
         ctx.embed_batch_dev(nimg, pc, w, h, pb, pbits, n_bits, po, center=center, rmax=rmax, usable_ptr=pu)
         ctx.sync()
-        assert np.array_equal(bufs.get(ub), ud) and np.array_equal(bufs.get(ob), sd), ("tile statistics (optional path)", env)
+        assert np.array_equal(bufs.get(ub), ud) and np.array_equal(bufs.get(ob), sd), ("statistics variants of the delta pipeline", env)
         ctx.close()
     assert np.array_equal(ud, u0)
     assert np.array_equal(bufs.get(cb), covers), "the cover buffer is read, never written"
