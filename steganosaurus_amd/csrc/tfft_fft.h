@@ -145,7 +145,25 @@ __device__ __forceinline__ float2 twload(const float2* __restrict__ tw, int j) {
 //   WaveSync : the whole sequence lives in ONE wave (N/E == 64).  DS instructions of a wave execute
 //              in issue order, so only the compiler has to be kept from reordering / caching: no
 //              s_barrier, waves of the workgroup run their passes independently.
-struct BlockSync { static __device__ __forceinline__ void sync() { __syncthreads(); } };
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope release/acquire fence around
+// s_barrier, and on gfx950 the release makes the compiler emit s_waitcnt vmcnt(0): EVERY global load in flight -- the prefetch of the
+// next column tile, the twiddles fetched ahead -- was drained at the first exchange of a transform (tools/dma_probe.hip: a one-tile-ahead
+// prefetch overlapped nothing, 0.47 ms where the raw barrier takes 0.31).  None of the transform kernels hands GLOBAL data from one
+// thread of a workgroup to another, so the barrier only has to order LDS: wait for this wave's own LDS operations, s_barrier, and a
+// compiler barrier on both sides.  (-DTFFT_RAW_BARRIER=0: the fenced form, for A/B runs; the CPU emulation always takes it.)
+#ifndef TFFT_RAW_BARRIER
+#define TFFT_RAW_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIPCC__) && TFFT_RAW_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+struct BlockSync { static __device__ __forceinline__ void sync() { lds_barrier(); } };
 struct WaveSync {
     static __device__ __forceinline__ void sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -195,7 +195,7 @@ k_rows_fwd(const uint8_t* __restrict__ rgb, float2* __restrict__ out, const floa
     float2 wk[NSPLIT];
 #pragma unroll
     for (int j = 0; j < NSPLIT; j++) wk[j] = tw[imin(t + j * T, M / 2)];
-    __syncthreads();
+    lds_barrier();
 
     // ---- complex FFT of length M on z[m] = x[2m] + i x[2m+1].  From here on a thread only touches
     // its own plane's LDS slab; when that plane is exactly one wave (T == 64) no workgroup barrier is needed.
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const ui
             ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
         }
     }
-    __syncthreads();                    // the twiddle table and every live row are staged
+    lds_barrier();                    // the twiddle table and every live row are staged
     // pass twiddles are read at the point of use from the LDS copy: prefetching them into registers
     // (54 more VGPRs) leaves room for one workgroup per CU instead of two and measured 0.87 ms against 0.66 ms
     if constexpr (T == 64) {            // one wave per row: the waves of padded rows skip the transform altogether
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_rowcol_fwd(const ui
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- real-FFT split and length-N1 DFT across the rows in one go, per column PAIR (x, M-x): the split
     // X[x] = Ev + w^x Od, X[M-x] = conj(Ev - w^x Od) needs Z[x] and Z[M-x] of the same row, and w^x is the same for
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_rowcol_fwd_live(cons
             ldsf[2 * lay.idx(n >> 1, n1) + (n & 1)] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
     {
         float2 u[E];
         if (live) {
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__((1 << (LOGM - 4)) * NL) k_rowcol_fwd_live(cons
 #pragma unroll
         for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, n1)] = live ? u[m] : make_float2(0.f, 0.f);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- real-FFT split + length-8 DFT across the rows per column pair (x, M-x); rows >= NL are zeros
     float2 wc[N1];
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(1 << (LOGM - 4 + LOGN1)) k_colrow_inv(const fl
     }
 #pragma unroll
     for (int i = 0; i < NT; i++) ltw[n1 * T + t + i * T * N1] = tv[i];
-    __syncthreads();
+    lds_barrier();
     const bool live = y < P.H;          // wave uniform (a row is one or two whole waves)
     if constexpr (T == 64) {            // one wave per row: no workgroup barrier follows, padded rows are done
         if (!live) return;
@@ -755,7 +755,7 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
     else fft_block<M, E, -1, Sync>(u, lds, lay, t, pb, W);
 #pragma unroll
     for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, pb)] = cscale(u[m], P.scale);
-    __syncthreads();
+    lds_barrier();
 
     // ---- quantise and store
     const int nbytes = P.W * 3;
@@ -902,16 +902,40 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     const int toff = ts > 1 ? P.tile_off : 0;
     const int ntiles = ((P.M + C - 1) / C - toff + ts - 1) / ts;
     const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
+    // The loads of a tile are UNCONDITIONAL at clamped (always valid) addresses; elements that do not exist (rows >= in_rows, the
+    // columns / groups beyond the grid) are zeroed by tile_mask() when the tile is consumed.  Written as `cond ? src[i] : 0` every
+    // load sat behind its own s_cbranch_execz, and a load that may or may not have been issued cannot be counted: the wait for
+    // the CURRENT tile's registers at the top of its transform became s_waitcnt vmcnt(<the few unconditional loads>), i.e. it
+    // also waited for the tile prefetched a moment earlier -- the one-tile-ahead prefetch never overlapped anything (rounds 1-2).
+    const int rows_in_max = P.in_a * (L - 1) + P.in_b * (P.G - 1);            // highest input row any thread of the launch addresses
+    const bool in_full = (rows_in_max < P.in_rows) && (P.M % C == 0) && (P.G % (int)blockDim.z == 0);
     auto load_tile = [&](int tile, float2 (&v)[E]) {
-        const int col = (tile * ts + toff) * C + c;
-        const bool active = (col < P.M) && (g < P.G) && (MODE != COLS_EMBED);
+        const int col = imin((tile * ts + toff) * C + c, P.M - 1);
         const float2* src = in + plane_off + col;
+        const int gc = imin(g, P.G - 1);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const int row = imin(P.in_a * (t + m * T) + P.in_b * gc, P.in_rows - 1);
+            v[m] = src[(size_t)row * P.M];
+        }
+    };
+    auto tile_mask = [&](int tile, float2 (&v)[E]) {       // workgroup-uniform test first: the final steps never need it
+        if (in_full) return;
+        const bool active = ((tile * ts + toff) * C + c < P.M) && (g < P.G);
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const int row = P.in_a * (t + m * T) + P.in_b * g;
-            v[m] = (active && row < P.in_rows) ? src[(size_t)row * P.M] : make_float2(0.f, 0.f);
+            if (!(active && row < P.in_rows)) v[m] = make_float2(0.f, 0.f);
         }
     };
+    float2 u[E], un[E];
+    // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
+    // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
+    float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
+    auto load_aw = [&](int tile) -> float2 { const int col = (tile * ts + toff) * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    // the first tile's loads go out before anything else: the tables staged below (each a global -> LDS round trip) ride behind them,
+    // and ONE barrier at the end of the prologue covers them all
+    if (MODE != COLS_EMBED) { load_tile(tile0, u); awc = load_aw(tile0); }
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
     float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
@@ -927,31 +951,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     if (TW) {
         for (int k = t * C + c; k < L; k += T * C) lds_wo[k] = twload<SIGN>(tw, (k * g) & (P.PH - 1));
     }
-    if (DC || TW) __syncthreads();
-    // COLS_READ: the buckets of this workgroup's tiles are consecutive (tile is the last digit of the bucket id), so
-    // nine offsets tell which tiles carry bins at all; a tile without bins (beyond the annulus: a tenth of them with
-    // rmax = 0.45) is neither loaded nor transformed.  Workgroup-uniform, so the barriers stay aligned.
-    constexpr int NOFF = 16;            // tiles per workgroup the skip test covers (the read variant walks 16, the others 8)
-    unsigned eoff[NOFF + 1];
-    if (MODE == COLS_READ) {
-        const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
-#pragma unroll
-        for (int i = 0; i <= NOFF; i++) eoff[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
-    }
-    auto has_bins = [&](int tile) -> bool {
-        if (MODE != COLS_READ || P.tiles_per_block > NOFF || blockDim.z > 1) return true;
-        const int i = tile - tile0;
-        bool r = true;
-#pragma unroll
-        for (int k = 0; k < NOFF; k++) if (k == i) r = eoff[k + 1] > eoff[k];
-        return r;
-    };
-    float2 u[E], un[E];
-    // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
-    // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
-    float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
-    auto load_aw = [&](int tile) -> float2 { const int col = (tile * ts + toff) * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
-    if (MODE != COLS_EMBED && has_bins(tile0)) { load_tile(tile0, u); awc = load_aw(tile0); }
+    // COLS_READ: a tile without bins (beyond the annulus: a tenth of them with rmax = 0.45) is neither loaded nor transformed.  The bucket
+    // offsets of the workgroup's tiles sit in LDS (lds_eo, staged below); workgroup-uniform, so the barriers stay aligned.  The FIRST tile
+    // is loaded before the offsets are there (its load must not wait for a global -> LDS round trip) and dropped afterwards if empty.
+    constexpr int NOFF = 16;            // tiles per workgroup the offsets cover (the launcher caps tiles_per_block of the bucket modes)
     // inter-pass twiddles: registers (fetched once per workgroup) for short columns; from TFFT_COLS_LDS_TW_LOG on the L-entry table
     // exp(+2 pi i j/L) is staged in LDS and read at the point of use (at L = 512 they would be 46 more VGPRs in a kernel capped at 256)
     constexpr bool TWL = (LOGL >= TFFT_COLS_LDS_TW_LOG);
@@ -961,7 +964,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     if (TWL) {
         const int tws = P.PH >> LOGL;
         for (int k = (gl * T + t) * C + c; k < L; k += blockDim.z * T * C) lds_tw[k] = tw[k * tws];
-        __syncthreads();
     } else {
         fft_prefetch_twiddles<L, E, SIGN>(W, t, tw, P.PH >> LOGL);
     }
@@ -977,7 +979,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // it: a load inside a predicated block is followed by its own s_waitcnt vmcnt(0) (32 serialised round trips were seen).
     // entries per thread that travel in registers.  4K: ~1650 entries per bucket and 512 threads, 1080p: ~240 and 256.  Four help the
     // forward step at 4K (0.78 -> 0.75 ms per 8-image launch) and cost the inverse step there (0.55 -> 0.60): it keeps two
-    constexpr int NE = (LOGL >= 9 && MODE != COLS_EMBED) ? 4 : 2;
+#ifndef TFFT_EMBED_NE9
+#define TFFT_EMBED_NE9 2
+#endif
+    constexpr int NE = (LOGL >= 9) ? (MODE == COLS_EMBED ? TFFT_EMBED_NE9 : 4) : 2;
     struct EmEntry { TileBin tb; float2 f; unsigned bit, live; };   // bucket entry, the stored value of its bin (conjugate of the bin when
                                                                     // tb.conj) and its stream bit (2: beyond the end of the stream)
     EmEntry enC[NE], enN[NE];
@@ -985,15 +990,21 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // the bucket offsets of the workgroup's tiles (at most NOFF: the launcher sees to it) sit in LDS: read with lgkmcnt, not vmcnt,
     // and without the branch trees a register array indexed by the tile turned into
     unsigned* lds_eo = reinterpret_cast<unsigned*>(lds_tw + (TWL ? L : 0) + blockDim.z * C) + gl * (NOFF + 2);
-    if (MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {
+    if (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
         for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
-        __syncthreads();
     }
+    lds_barrier();            // the tables above (DC rows, output twiddles, pass twiddles, bucket offsets)
     auto em_range = [&](int tile, unsigned& e0, unsigned& e1) {
         const int i = imin(tile - tile0, NOFF - 1);
         e0 = lds_eo[i]; e1 = lds_eo[i + 1];
         if (!(tile < tile1 && g < P.G)) e1 = e0;
+    };
+    auto has_bins = [&](int tile) -> bool {
+        if (MODE != COLS_READ || blockDim.z > 1) return true;
+        unsigned e0, e1;
+        em_range(tile, e0, e1);
+        return e1 > e0;
     };
     const float2* em_fl = P.em_fl + (size_t)img * P.em_n;
     const uint8_t* em_pb = P.em_pb + (size_t)img * P.em_n;
@@ -1070,10 +1081,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         }
     };
     if (MODE == COLS_EMBED) em_entries(tile0, enC, true);
-    if (MODE == COLS_EMIT || MODE == COLS_STAT) em_entries(tile0, enC, false);
+    if (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ) em_entries(tile0, enC, false);
     for (int tile = tile0; tile < tile1; tile++) {
         if (MODE != COLS_EMBED && tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
-        if (MODE == COLS_EMIT || MODE == COLS_STAT) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
+        if (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
         if (MODE == COLS_EMBED) {
             // the tile of F' - F: zeros but for the bins of the list (S:712-732 per bin); a tile without bins is stored as zeros.
             // The values of tile+1's bins and the entries of tile+2 are fetched now (see em_* above the loop).
@@ -1083,7 +1094,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             if (hb) {
 #pragma unroll
                 for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = make_float2(0.f, 0.f);
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int i = 0; i < NE; i++)
                     if (enC[i].live && enC[i].bit < 2u) lds[lay.idx(enC[i].tb.k, enC[i].tb.c)] = em_delta(enC[i].f, enC[i].bit, enC[i].tb.conj);
@@ -1097,10 +1108,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                         lds[lay.idx(tb.k, tb.c)] = em_delta(em_fl[e], bit, tb.conj);
                     }
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int m = 0; m < E; m++) u[m] = lds[lay.idx(t + m * T, c)];
-                __syncthreads();            // before the first exchange of the transform overwrites the tile
+                lds_barrier();            // before the first exchange of the transform overwrites the tile
                 if (TWL) fft_block_lazy<L, E, SIGN>(u, lds, lay, t, c, lds_tw, 1);
                 else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
             }
@@ -1126,8 +1137,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
             awc = awn;
+#pragma unroll
+            for (int i = 0; i < NE; i++) enC[i] = enN[i];
             continue;
         }
+        tile_mask(tile, u);
         if (DC && SIGN < 0) {           // first inverse step: the rank-1 term leaves before the transform (the row kernel adds c back)
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = csub(u[m], cmul(lds_ah[t + m * T], awc));
@@ -1136,30 +1150,35 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
         if (MODE == COLS_READ) {
             // park the tile (row k of group g = spectrum row g + G*k) and read the bits of its bins in place
-            __syncthreads();            // the last gather of fft_block has been consumed by every thread
+            lds_barrier();            // the last gather of fft_block has been consumed by every thread
 #pragma unroll
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             // DC removal: the rank-1 term is added to the bins that are READ (a few hundred per tile), not to all 16 x L values of
             // the tile (that was 0.056 ms of the 0.50 ms launch): the tile's 16 column factors go to LDS beside the row factors
             if (DC && t == 0) lds_aw[c] = awc;
-            __syncthreads();
+            lds_barrier();
             if (g < P.G) {
-                const unsigned b = (unsigned)((plane * P.G + g) * ntiles + tile);
-                const unsigned e0 = P.rd_off[b], e1 = P.rd_off[b + 1];
+                // the tile's entries travelled with its loads (NE per thread in registers; a longer bucket fetches the rest in place)
+                unsigned e0, e1;
+                em_range(tile, e0, e1);
                 uint8_t* bo = P.rd_bits + (size_t)img * P.rd_n;
-                const int tid = t * C + c, nthr = T * C;
-                for (unsigned e = e0 + tid; e < e1; e += nthr) {
-                    const TileBin tb = P.rd_bins[e];
+                auto read_one = [&](const TileBin tb) {
                     float2 v = lds[lay.idx(tb.k, tb.c)];
                     if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
                     if (tb.conj) v = cconj(v);
                     bo[tb.bit] = (uint8_t)(P.rd_generic ? read_bit_value(v, *P.rd_ep, plane, P.rd_jitter, tb.bit) : (v.y >= 0.0f ? 1 : 0));
-                }
+                };
+#pragma unroll
+                for (int i = 0; i < NE; i++)
+                    if (enC[i].live) read_one(enC[i].tb);
+                for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) read_one(P.rd_bins[e]);
             }
-            __syncthreads();            // before the next tile's exchanges overwrite the parked values
+            lds_barrier();            // before the next tile's exchanges overwrite the parked values
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
             awc = awn;
+#pragma unroll
+            for (int i = 0; i < NE; i++) enC[i] = enN[i];
             continue;
         }
         const int col = (tile * ts + toff) * C + c;
@@ -1189,11 +1208,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         if (MODE == COLS_EMIT || MODE == COLS_STAT) {
             // park the tile (as COLS_READ does) and write the values of the listed bins, DC term included, into the list the first
             // inverse step embeds from: em_fl[entry index], coalesced
-            __syncthreads();            // the last gather of fft_block has been consumed by every thread
+            lds_barrier();            // the last gather of fft_block has been consumed by every thread
 #pragma unroll
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             if (DC && t == 0) lds_aw[c] = awc;
-            __syncthreads();
+            lds_barrier();
             if (MODE == COLS_STAT) {
                 // the bracket pass of the statistics (k_collect_bracket's classify / cap_elem) on the parked tile: one value = one stored
                 // bin (row, col) of weight 2; the packed column 0 is left to k_col0_stats.  A rolled loop over LDS: unrolled over the
@@ -1232,7 +1251,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                     fl[e] = v;
                 }
             }
-            __syncthreads();            // before the next tile's exchanges overwrite the parked values
+            lds_barrier();            // before the next tile's exchanges overwrite the parked values
 #pragma unroll
             for (int i = 0; i < NE; i++) enC[i] = enN[i];
         }
@@ -1244,11 +1263,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         if (st_nstaged) st_flush();
         if (st_below) atomicAdd(&st_s->below, (unsigned long long)st_below);
         if (P.st_cap) {          // one count per workgroup
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) st_wcnt[0] = 0;
-            __syncthreads();
+            lds_barrier();
             if (st_capcount) atomicAdd(&st_wcnt[0], st_capcount);
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0 && st_wcnt[0])
                 atomicAdd(&P.st_partial[((size_t)img * 3 + plane) * TFFT_STAT_MAX_BLOCKS + ((blockIdx.y * gridDim.x + blockIdx.x) % TFFT_STAT_MAX_BLOCKS)], st_wcnt[0]);
         }
@@ -2539,16 +2558,17 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
     const size_t lds0 = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
-                       (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0) + ((MODE == COLS_READ && DC) ? (size_t)gpb * C * sizeof(float2) : 0);
+                       (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C;
     int tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     ColParams Q = P;
-    if (MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
+    constexpr bool BUCKETS = (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT);
+    if (BUCKETS) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
         if (tpb > 16) tpb = 16;
         Q.tiles_per_block = tpb;
     }
     const size_t nwaves = ((size_t)C * T * gpb + 63) / 64;
-    const size_t lds = lds0 + ((MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
+    const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
                        (MODE == COLS_STAT ? (nwaves * 257 + 1) * sizeof(unsigned) : 0);
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
