@@ -82,11 +82,6 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
         # in, 1 B out); the last forward step also writes the listed bins' values (entry 8 B in, value 8 B out); the first inverse
         # step reads entry + value + bit instead of the spectrum and only WRITES its planes; the row kernel also reads the cover
         final_fwd = "cols_fwd_b" if two_step else "cols_fwd_a"
-        tile = plan.get("tile_stats", False)
-        # tile statistics: the bracket pass of the medians / capacity runs inside the last forward column step
-        # on the LDS-resident tiles and the spectrum is never stored; ~13 % of the bins are bracket candidates (4 B each, written there,
-        # read twice by the select kernels); every 8th column tile is transformed once more beforehand as the sample
-        cand = int(0.13 * 3 * PH * M) * 4
         if stage == "embed":
             return n_bits * (8 + 1 + 1)
         m2 = plan.get("m2", False)      # the spectrum is stored as |F|^2 (4 B per bin): all the statistics read, and nothing else reads it
@@ -94,12 +89,9 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
             rd = (3 * plane_full) if two_step else 3 * plane_h
             if plan.get("no_store", False):      # no capacity asked for (--no-stats): nobody reads the spectrum, nothing is stored
                 return rd + n_bits * (8 + 8)
-            return rd + (cand if tile else (3 * plane_full // 2 if m2 else 3 * plane_full)) + n_bits * (8 + 8)
-        if stage == "medians" and m2 and not tile:
+            return rd + (3 * plane_full // 2 if m2 else 3 * plane_full) + n_bits * (8 + 8)
+        if stage == "medians" and m2:
             return int(3 * (plane_full // 2) * (1 + 1.0 / 16))
-        if stage == "medians" and tile:
-            rd = (3 * plane_full) if two_step else 3 * plane_h
-            return rd // 8 + 2 * (3 * plane_full // 8) + 2 * cand
         if stage == "cols_inv_a":
             return (3 * plane_full if two_step else 3 * plane_h) + n_bits * (8 + 8 + 1)
         if stage == "rows_inv":
@@ -201,11 +193,8 @@ class Workload:
         self.plan = self.ctx.plan_info(W, H, min(self.slots, n_img))      # which kernels a launch over the chunk takes
         self.plan["delta"] = int(os.environ.get("TFFT_EMBED_DELTA", "1")) != 0      # the bin list is registered below: delta embedding applies
         PHp, PWp = next_pow2(H), max(2, next_pow2(W))
-        self.plan["m2"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0 and int(os.environ.get("TFFT_STATS_TILE", "0")) == 0
-                           and PHp * PWp <= (1 << 24))
+        self.plan["m2"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0 and PHp * PWp <= (1 << 24))
         self.plan["no_store"] = self.plan["delta"] and not stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0
-        self.plan["tile_stats"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_TILE", "0")) != 0 and self.plan["log_n2"] <= 9
-                                   and PHp * PWp <= (1 << 24))
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.h_index = d_index.cpu().numpy().astype(np.uint32) if self.sort_bins else None
         if self.sort_bins:

@@ -54,27 +54,19 @@ struct tfft_ctx {
     float2* spec_pool = nullptr;
     float2* tmp_pool = nullptr;
     unsigned* cand_pool = nullptr;
-    float2* mini_pool = nullptr;          // [n_slots*3*max_ph*mini_cols] the sample of column tiles the tile statistics guess their bracket from
-    size_t mini_cols = 0;
-    float2* col0_pool = nullptr;          // [n_slots*3*max_ph] the packed column 0 as the COLS_STAT step leaves it
-    int stats_tile = 0;                   // TFFT_STATS_TILE=1: batched delta embeds run the statistics' bracket pass inside the last forward column
-                                          // step and never store the spectrum.  Measured SLOWER than storing it and running the statistics
-                                          // kernels over it (32 x 1080p: the step 0.75 vs 0.65 ms, the rest of the statistics 0.43 vs 0.41 ms;
-                                          // 8 x 4K: 0.98 vs 0.77 and 0.37 vs 0.40): the step is LDS/VALU bound, not store bound.  Kept as an option.
-    int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
-    int stats_tile_skew = 0;              // test hook: brackets moved by this many buckets (the fast path fails, the gated fallback runs)
-    const ColParams* fwd_plain_extra = nullptr;   // final forward step: tile_step / out_* (sample) or gate fields, and ...
-    float2* fwd_out_override = nullptr;           // ... its output buffer
+    float2* col0_pool = nullptr;          // [n_slots*3*max_ph] the packed column 0 of batched embeds that store |F|^2 planes (ColParams::st_col0)
+    int stats_skew = 0;                   // test hook (TFFT_STATS_SKEW): brackets moved by this many buckets -- the fast path fails, the fallbacks run
     SelectState* sel = nullptr;           // [n_slots*3]
     float* med = nullptr;                 // [n_slots*3]
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS + n_slots]
     float* amb = nullptr;                 // [n_slots*3*TFFT_AMB_CAP] |F|^2 of the bins the bracket pass could not decide
     unsigned long long* usable = nullptr; // [n_slots]
     int* err = nullptr;                   // sticky bin-range flag
+    uint8_t* trash = nullptr;             // 8 KiB nobody reads: target of the unpredicated list stores of lanes without an entry (ColParams::trash)
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
     // spectrum-free extraction (k_fft_cols<..., COLS_READ>): the bin list bucketed by column tile, per compute stream
     struct TileBuckets { float2* fl = nullptr; uint8_t* pb = nullptr; uint64_t fl_cap = 0;      /* delta embedding: values of the listed bins, n_slots x n (ColParams::em_fl) */
-                         unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; EmbedParams* ep = nullptr; EmbedParams ep_host; uint64_t cap = 0; int nb_cap = 0;
+                         unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; uint64_t cap = 0; int nb_cap = 0;
                          // what the buckets / the last-row scalar currently describe (tfft_bins_register_dev: reused while the registered list is the one passed in)
                          const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr;
                          const void* row_for = nullptr; uint64_t row_n = 0; int row_ph = 0, row_pw = 0; } tb[2];
@@ -214,15 +206,9 @@ int get_dc_table(tfft_ctx* c, int valid, int N, int center, int kind, double sca
 void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw device pointers: dropped whenever a buffer is reallocated
 
 static void copy_embed_fields(ColParams& cp, const ColParams& e) {
-    cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off;
+    cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off; cp.trash = e.trash;
     cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1; cp.em_m2 = e.em_m2;
-    cp.st_sel = e.st_sel; cp.st_cand = e.st_cand; cp.st_cand_stride = e.st_cand_stride; cp.st_partial = e.st_partial; cp.st_amb = e.st_amb;
-    cp.st_col0 = e.st_col0; cp.st_slo = e.st_slo; cp.st_shi = e.st_shi; cp.st_cap = e.st_cap; cp.st_PW = e.st_PW;
-}
-
-static void copy_plain_extra(ColParams& cp, const ColParams& e) {
-    if (e.tile_step > 1) cp.tiles_per_block = 1;      // the sample: an eighth of the tiles, one per workgroup keeps the grid wide
-    cp.tile_step = e.tile_step; cp.tile_off = e.tile_off; cp.out_M = e.out_M; cp.out_plane_stride = e.out_plane_stride; cp.out_img_stride = e.out_img_stride; cp.gate = e.gate;
+    cp.st_col0 = e.st_col0;
 }
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
@@ -255,10 +241,9 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
+                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
                 else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
-                else if (c->fwd_plain_extra) copy_plain_extra(cp, *c->fwd_plain_extra);
-                HIPCHK(c, launch_cols(tmp, c->fwd_out_override ? c->fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+                HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
                 HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, +1, 3 * n, st));
@@ -273,10 +258,9 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.rd_jitter = r.rd_jitter; cp.rd_ep = r.rd_ep; cp.rd_generic = r.rd_generic; cp.tiles_per_block = c->cols_tiles_read; }
+            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
             else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
-            else if (c->fwd_plain_extra) copy_plain_extra(cp, *c->fwd_plain_extra);
-            HIPCHK(c, launch_cols(tmp, c->fwd_out_override ? c->fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+            HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
@@ -413,7 +397,7 @@ int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams*
     HIPCHK(c, launch_medians(c->spec(s0), s.PH, s.PWi, c->slot_stride, n, c->sel + 3 * s0,
                              c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0, c->median_force_fallback, c->n_cus, c->collect_resident, st,
                              cap, partial, c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable, c->stats_compact,
-                             m2 ? c->col0_pool + (size_t)s0 * 3 * s.PH : nullptr, c->stats_tile_skew));
+                             m2 ? c->col0_pool + (size_t)s0 * 3 * s.PH : nullptr, c->stats_skew));
     return TFFT_OK;
 }
 // the batched delta embeds with capacity: may the last forward step store |F|^2 instead of the spectrum?
@@ -544,12 +528,9 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_FUSE_WIDE")) c->fuse_wide = atoi(e);
     if (const char* e = getenv("TFFT_FUSE_LIVE")) c->fuse_live = atoi(e);
     if (const char* e = getenv("TFFT_EMBED_DELTA")) c->embed_delta = atoi(e);
-    if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
     if (const char* e = getenv("TFFT_STATS_ASYNC")) c->stats_async = atoi(e);
     if (const char* e = getenv("TFFT_STATS_M2")) c->stats_m2 = atoi(e);
-    if (const char* e = getenv("TFFT_STATS_TILE_SKEW")) c->stats_tile_skew = atoi(e);
-    if (const char* e = getenv("TFFT_STATS_SKEW")) c->stats_tile_skew = atoi(e);
-    if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
+    if (const char* e = getenv("TFFT_STATS_SKEW")) c->stats_skew = atoi(e);
     if (const char* e = getenv("TFFT_STREAMS")) c->n_streams = atoi(e);
     if (const char* e = getenv("TFFT_TILE_READ")) c->tile_read = atoi(e);
     if (const char* e = getenv("TFFT_DC_BIAS")) c->dc_bias = (float)atof(e);
@@ -574,7 +555,6 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
-    c->mini_cols = M / 8 + 16;          // (mini_pool itself is allocated by the first call that uses the optional tile statistics)
     if (!rc) rc = dev_alloc(c, (void**)&c->col0_pool, ns * 3 * (size_t)ph * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
@@ -582,6 +562,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->amb, ns * 3 * TFFT_AMB_CAP * sizeof(float));
     if (!rc) rc = dev_alloc(c, (void**)&c->usable, ns * sizeof(unsigned long long));
     if (!rc) rc = dev_alloc(c, (void**)&c->err, sizeof(int));
+    if (!rc) rc = dev_alloc(c, (void**)&c->trash, 8192);
     if (!rc) rc = dev_alloc(c, (void**)&c->last_row, 2 * sizeof(int));
     if (!rc && hipMemset(c->err, 0, sizeof(int)) != hipSuccess) rc = TFFT_E_HIP;
     if (!rc && hipMemset(c->sel, 0, ns * 3 * sizeof(SelectState)) != hipSuccess) rc = TFFT_E_HIP;      // the compact statistics pipeline starts from clean histograms
@@ -597,9 +578,9 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipDeviceSynchronize();
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->mini_pool); (void)hipFree(c->col0_pool);
-    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
-    for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.ep); (void)hipFree(b.fl); (void)hipFree(b.pb); }
+    (void)hipFree(c->col0_pool);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->trash); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
+    for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->dc) (void)hipFree(kv.second);
     (void)hipFree(c->stage_bins); (void)hipFree(c->stage_bits); (void)hipFree(c->stage_jit); (void)hipFree(c->stage_out);
@@ -883,7 +864,6 @@ static int ensure_buckets(tfft_ctx* c, int which, uint64_t n, int nb, bool with_
             return TFFT_E_NOMEM;
         b.nb_cap = nb + 1;
     }
-    if (!b.ep && dev_alloc(c, (void**)&b.ep, sizeof(EmbedParams))) return TFFT_E_NOMEM;
     if (with_values && (n * (uint64_t)c->n_slots > b.fl_cap || !b.fl)) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -910,74 +890,6 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 }
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
-// forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
-// phases (tfft_profile_stage times them apart): 1 the steps before the last column step, 2 sample + bracket guess, 4 the COLS_STAT step,
-// 8 select + gated spectrum + fallbacks + capacity
-static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, hipStream_t st, ColParams& em, const CapParams& cap,
-                                     unsigned long long* usable, int phases = 15) {
-    const Slot& s = c->slots[s0];
-    const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
-    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
-    // the sample: column tiles off, off + step, ..  -- centred in their strides (tiles 0, step, .. sit at the low-frequency end of every
-    // stride and read a median several per cent too high: the bracket missed on every padded image)
-    const int M = s.PWi / 2, ntiles = (M + 15) / 16, step = c->stats_tile_step;
-    const int off = ntiles > step / 2 ? step / 2 : 0;
-    const int Ms = 16 * ((ntiles - off + step - 1) / step);
-    if ((size_t)Ms > c->mini_cols) return TFFT_E_STATE;
-    if (!c->mini_pool) {
-        (void)hipStreamSynchronize(c->stream);
-        invalidate_graphs(c);
-        if (dev_alloc(c, (void**)&c->mini_pool, (size_t)c->n_slots * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols * sizeof(float2))) return TFFT_E_NOMEM;
-    }
-    int rc;
-    for (int stage : {ROWS_FWD, COLS_FWD_A}) {
-        if (stage == final_fwd || !(phases & 1)) break;
-        rc = enqueue_fft_stage(c, s0, g, stage, rgb_in, nullptr, st);
-        if (rc) return rc;
-    }
-    float2* mini = c->mini_pool + (size_t)s0 * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols;
-    float2* col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
-    SelectState* sel = c->sel + 3 * s0;
-    unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
-    float* amb = c->amb + (size_t)3 * s0 * TFFT_AMB_CAP;
-    unsigned* cand = c->cand_pool + (size_t)3 * s0 * c->cand_stride;
-    // (1) every step-th column tile -> a narrow spectrum; its histogram brackets the medians
-    ColParams ex{};
-    ex.tile_step = step; ex.tile_off = off; ex.out_M = Ms; ex.out_plane_stride = (size_t)s.PH * Ms; ex.out_img_stride = (size_t)3 * s.PH * Ms;
-    const ColParams* emit = c->fwd_emit;
-    if (phases & 2) {
-        c->fwd_emit = nullptr; c->fwd_plain_extra = &ex; c->fwd_out_override = mini;
-        rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
-        c->fwd_plain_extra = nullptr; c->fwd_out_override = nullptr; c->fwd_emit = emit;
-        if (rc) return rc;
-        HIPCHK(c, launch_stat_guess(mini, s.PH, s.PWi, Ms, ex.out_img_stride, g, sel, &cap, partial, off == 0 ? 1 : 0, st));
-        if (c->stats_tile_skew) HIPCHK(c, launch_skew_bracket(sel, g, c->stats_tile_skew, st));
-    }
-    // (2) the last forward step: values of the listed bins + the bracket pass on every value
-    if (phases & 4) {
-    em.st_sel = sel; em.st_cand = cand; em.st_cand_stride = c->cand_stride; em.st_partial = partial; em.st_amb = amb; em.st_col0 = col0;
-    em.st_slo = cap.s_lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_lo; em.st_shi = cap.s_hi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_hi;
-    em.st_cap = 1; em.st_PW = cap.PW;
-    c->fwd_emit = &em;
-    rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
-    c->fwd_emit = emit;
-    em.st_sel = nullptr;
-    if (rc) return rc;
-    }
-    if (!(phases & 8)) return TFFT_OK;
-    HIPCHK(c, launch_stat_select(s.PH, g, sel, cand, c->cand_stride, c->med + 3 * s0, col0, st));
-    // (3) images with a plane the fast path could not settle: their spectrum after all (the others return at once), then the fallbacks
-    ColParams gt{};
-    gt.gate = sel;
-    c->fwd_emit = nullptr; c->fwd_plain_extra = &gt;
-    rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st);
-    c->fwd_plain_extra = nullptr; c->fwd_emit = emit;
-    if (rc) return rc;
-    HIPCHK(c, launch_stat_settle(c->spec(s0), s.PH, s.PWi, c->slot_stride, g, sel, c->med + 3 * s0, &cap, partial, amb, usable, st));
-    for (int i = 0; i < g; i++) { c->slots[s0 + i].has_spec = false; c->slots[s0 + i].rgb_src = nullptr; }
-    return TFFT_OK;
-}
-
 struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
@@ -1004,7 +916,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         rc = build_buckets(c, which, bins, n_bits, s, G, st);
         if (rc) return rc;
         auto& tb = c->tb[which];
-        em.rd_bins = tb.ent; em.rd_off = tb.off; em.em_fl = tb.fl + (size_t)s0 * n_bits; em.em_pb = tb.pb + (size_t)s0 * n_bits;
+        em.rd_bins = tb.ent; em.rd_off = tb.off; em.trash = c->trash; em.em_fl = tb.fl + (size_t)s0 * n_bits; em.em_pb = tb.pb + (size_t)s0 * n_bits;
         em.em_n = n_bits; em.em_cos = ep.cos_a; em.em_sin = ep.sin_a;
         if (usable) {
             CapParams p0 = cap_params(c, s, rmin, rmax);
@@ -1016,23 +928,6 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
         c->fwd_emit = &em;
-    }
-    if (delta && usable && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback) {
-        // the statistics' bracket pass inside the last forward column step: the spectrum is never stored (unless a plane's bracket
-        // turns out wrong: then the gated plain step produces it for the fallback kernels)
-        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
-        CapParams p = cap_params(c, s, rmin, rmax);
-        p.magmin = magmin;
-        if (p.bw > 0 && pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24)) {
-            em.em_m2 = 0;
-            rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable);
-            c->fwd_emit = nullptr;
-            if (rc) return rc;
-            c->inv_embed = &em; c->inv_cover = rgb_in;
-            rc = enqueue_inverse(c, s0, g, rgb_out, st);
-            c->inv_embed = nullptr; c->inv_cover = nullptr;
-            return rc;
-        }
     }
     rc = enqueue_forward(c, s0, g, rgb_in, st);
     c->fwd_emit = nullptr;
@@ -1085,7 +980,8 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
     // a registered list keeps its buckets (no per-call build to pay for): then the tile-resident read also serves small chunks of LARGE
     // images (one 4K image: 0.739 -> 0.725 ms per round trip; one 1080p image has too few tiles to fill the chip: 0.265 -> 0.301)
     const bool reg_large = bins == c->reg_bins && n_bits == c->reg_n && (unsigned long long)s.PH * s.PWi >= (1ull << 23);
-    if (c->tile_read && n_bits > 0 && (g >= 8 || c->tile_read >= 2 || reg_large)) {
+    // (an alpha outside (0, pi) takes the general phase comparison of k_read: the tile kernel reads the sign of Im only)
+    if (c->tile_read && n_bits > 0 && !ep.generic && (g >= 8 || c->tile_read >= 2 || reg_large)) {
         // The spectrum is only ever read at the bins of the list: bucket them by column tile and let the final
         // forward column step read the bits out of its LDS-resident tiles -- no spectrum store, no k_read.
         const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
@@ -1097,9 +993,7 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
         rc = build_buckets(c, which, bins, n_bits, s, G, st);
         if (rc) return rc;
         ColParams rd{};
-        rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.rd_jitter = nullptr;
-        rd.rd_generic = ep.generic; rd.rd_ep = tb.ep;
-        if (ep.generic) { tb.ep_host = ep; HIPCHK(c, hipMemcpyAsync(tb.ep, &tb.ep_host, sizeof ep, hipMemcpyHostToDevice, st)); }
+        rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.trash = c->trash;
         c->fwd_read = &rd;
         rc = enqueue_forward(c, s0, g, rgb_in, st);
         c->fwd_read = nullptr;
@@ -1500,14 +1394,9 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
         delta = !ep0.generic;
     }
-    // ... and their statistics run inside the last forward column step (enqueue_forward_tilestats): that step is timed as the pipeline
-    // runs it (final forward stage), everything else of the statistics under MEDIANS
     CapParams tcap = cap_params(c, s, 0.05, 0.45);
     tcap.magmin = 0.01;
-    const bool tile = delta && bits_dev && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback && tcap.bw > 0 &&
-                      pl.log_n2 <= 9 && (unsigned long long)s.PH * s.PWi <= (1ull << 24);
-    const bool m2 = delta && bits_dev && !tile && stats_m2_applies(c, s, tcap);      // the spectrum is stored as |F|^2 + column 0 (see embed_chunk)
-    if (tile && stage == MEDIANS) launches = 11;       // sample step, histogram, guess (+ memset), 5 select kernels, gated step, fallback, settle
+    const bool m2 = delta && bits_dev && stats_m2_applies(c, s, tcap);      // the spectrum is stored as |F|^2 + column 0 (see embed_chunk)
 
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
@@ -1522,13 +1411,13 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
             int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G);
             if (rc) return rc;
             HIPCHK(c, launch_bucket_bins((const tfft_bin*)bins_dev, c->bit_index, n_bits, s.PH, s.PWi, G, c->tb[0].cnt, c->tb[0].off, c->tb[0].ent, c->err, c->tile_read == 2, c->stream));
-            rd.rd_bins = c->tb[0].ent; rd.rd_off = c->tb[0].off; rd.rd_bits = (uint8_t*)bits_out_dev; rd.rd_n = n_bits; rd.rd_ep = c->tb[0].ep;
+            rd.rd_bins = c->tb[0].ent; rd.rd_off = c->tb[0].off; rd.rd_bits = (uint8_t*)bits_out_dev; rd.rd_n = n_bits; rd.trash = c->trash;
         } else {
             HIPCHK(c, launch_bins_last_row((const tfft_bin*)bins_dev, n_bits, s.PH, s.PWi, c->last_row, c->stream));
         }
     }
     ColParams em{};
-    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED || (stage == MEDIANS && tile)) && delta && bits_dev) {
+    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED) && delta && bits_dev) {
         if (!index_ok(c, n_bits)) return TFFT_E_STATE;
         const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16;
         int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G, true);
@@ -1536,28 +1425,9 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         rc = build_buckets(c, 0, (const tfft_bin*)bins_dev, n_bits, s, G, c->stream);
         if (rc) return rc;
         const EmbedParams ep0 = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
-        em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
+        em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.trash = c->trash; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
         em.em_cos = ep0.cos_a; em.em_sin = ep0.sin_a;
         if (m2) { em.em_m2 = 1; em.st_col0 = c->col0_pool; }
-    }
-    if (tile && (stage == final_fwd || stage == MEDIANS)) {
-        float ms_all = 0.f, ms_c = 0.f;
-        int rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 2);      // a valid bracket for the timed step
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
-        for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 4); if (rc) return rc; }
-        HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
-        HIPCHK(c, hipEventSynchronize(c->ev_t1));
-        HIPCHK(c, hipEventElapsedTime(&ms_c, c->ev_t0, c->ev_t1));
-        if (stage == MEDIANS) {      // the whole complex minus its COLS_STAT step
-            HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
-            for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 14); if (rc) return rc; }
-            HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
-            HIPCHK(c, hipEventSynchronize(c->ev_t1));
-            HIPCHK(c, hipEventElapsedTime(&ms_all, c->ev_t0, c->ev_t1));
-            *ms_per_rep = (ms_all - ms_c) / (float)reps;
-        } else *ms_per_rep = ms_c / (float)reps;
-        return TFFT_OK;
     }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {

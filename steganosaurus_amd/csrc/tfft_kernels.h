@@ -37,9 +37,7 @@ struct ColParams {
     const unsigned* rd_off;          // bucket b = (plane*G + g)*ntiles + tile holds rd_bins[rd_off[b] .. rd_off[b+1])
     uint8_t* rd_bits;                // bits_out, image i at rd_bits + i*rd_n
     uint64_t rd_n;
-    const float* rd_jitter;          // per stream bit, or nullptr
-    const struct EmbedParams* rd_ep; // device copy of the read parameters (generic path only dereferences it)
-    int rd_generic;
+    uint8_t* trash;                  // >= 8 KiB of device scratch nobody reads: where lanes WITHOUT a list entry send their (unpredicated) stores
     // delta embedding: the LAST forward step (COLS_EMIT) writes the values of the bucketed bins (rd_bins / rd_off as above) to em_fl
     // in bucket order; the FIRST inverse step (COLS_EMBED) starts every tile as zeros and puts F' - F at those bins, F taken from
     // em_fl (S:712-732 with a fixed alpha)
@@ -49,20 +47,8 @@ struct ColParams {
     const uint8_t* em_pb;            // COLS_EMBED: em_n stream bits per image in the same order (k_gather_bits; 2 = not written)
     uint64_t em_n;                   // list stride between images (the length of the bin list)
     float em_cos, em_sin;
-    // statistics inside the last forward step (COLS_STAT = COLS_EMIT without the spectrum store): every value is classified against
-    // the bracket of its plane's SelectState exactly as k_collect_bracket does (weight below, candidates, capacity counts, parked
-    // values); the packed column 0 goes to st_col0 for k_col0_stats
-    struct SelectState* st_sel;      // 3 per image
-    unsigned* st_cand; size_t st_cand_stride;
-    unsigned* st_partial;            // per (image, plane) TFFT_STAT_MAX_BLOCKS counters (a workgroup adds to slot block % that)
-    float* st_amb;
-    float2* st_col0;                 // per (image, plane) PH values
-    unsigned st_slo, st_shi;         // squared radius bounds of the annulus, clamped to 32 bits
-    int st_cap, st_PW;
-    // forward COLS_PLAIN only: a sample of the tiles (0, tile_step, 2*tile_step, ..) written side by side into a narrow spectrum
-    int tile_step, tile_off; int out_M; size_t out_plane_stride, out_img_stride;      // tiles tile_off + i*tile_step
-    // forward COLS_PLAIN only: images whose statistics were settled without the spectrum (all three planes) return at once
-    const struct SelectState* gate;
+    float2* st_col0;                 // COLS_EMIT with em_m2: per (image, plane) PH values, the packed column 0 (its two real spectra cannot be
+                                     // separated from magnitudes, so it travels beside the |F|^2 plane)
     int em_on;
     // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
     // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off
@@ -155,12 +141,6 @@ hipError_t audit_load_rgb8_f64(const uint8_t* rgb_dev, int W, int H, int PW, int
 hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, uint64_t n, int PH, int PW, int G,
                               unsigned* cnt, unsigned* off, TileBin* out, int* err, int force_global, hipStream_t s);
 // highest stored row any bin of the list touches -> *last_row (device int, reset here)
-hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t mini_img_stride, int n_images, SelectState* st, const struct CapParams* cap,
-                             unsigned* partial, int col0_packed, hipStream_t s);
-hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s);
-hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s);
-hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st, float* med_out, const struct CapParams* cap,
-                              unsigned* partial, float* amb, unsigned long long* usable, hipStream_t s);
 hipError_t launch_gather_bits(const TileBin* ent, const unsigned* n_ent, const uint8_t* bits, const uint8_t* hdr, const uint8_t* pay, uint64_t plen,
                               uint64_t n, uint64_t limit, int n_images, uint8_t* out, hipStream_t s);
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);

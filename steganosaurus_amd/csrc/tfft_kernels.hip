@@ -35,6 +35,11 @@
 #ifndef TFFT_COLS_WAVES
 #define TFFT_COLS_WAVES(logl) 1
 #endif
+// column kernels of length <= 2^this fetch the next tile into registers while the current one is transformed; longer ones do not
+// prefetch and rely on a second resident workgroup instead (see k_fft_cols)
+#ifndef TFFT_COLS_PF_MAXLOG
+#define TFFT_COLS_PF_MAXLOG 10
+#endif
 #ifndef TFFT_ROWS_LAZY_LOG
 #define TFFT_ROWS_LAZY_LOG 11
 #endif
@@ -869,8 +874,9 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 //                  bucketed to it (F read from `in` at those bins only) and is transformed: the stego image is cover + IFFT(F' - F),
 //                  so neither k_embed's scattered read-modify-write nor this step's read of the whole spectrum takes place
 //   COLS_EMIT      delta embedding (last forward step): the transform, plus the values of the listed bins written to P.em_fl
-//   COLS_STAT      COLS_EMIT without the spectrum store, with the statistics' bracket pass done on the values in registers (ColParams::st_*)
-enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4, COLS_STAT = 5 };
+// (round 2 also had COLS_STAT: COLS_EMIT without the spectrum store, the statistics' bracket pass done on the parked tile.  Identical
+//  results, measured slower -- 3.41 vs 3.30 ms per 32 x 1080p round trip, 4.42 vs 4.30 per 8 x 4K -- and removed in round 3.)
+enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4 };
 __device__ __forceinline__ unsigned wave_rank_of(unsigned long long m) {       // rank of this lane among the set bits of a wave mask
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -878,8 +884,11 @@ __device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header
 // DC: the DC-removal epilogue (ColParams::dc_*) is compiled in; its own instantiation, because the kernel sits at the
 // 256-VGPR cap and even the unused code costs accumulation-register spills
 // TW: the output twiddles of the two-step decomposition (P.tw_out) are compiled in: 32 VGPRs the final steps do not need
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false>
-__global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COLS_WAVES(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
+// FULL: every output element of the launch exists (all columns, groups and rows < out_rows): the stores carry no predicate.  A store
+//       behind an exec-mask branch may or may not have been issued, so s_waitcnt cannot count past it: the wait for the prefetched
+//       tile that follows then also waits for the stores just issued (their whole latency, every tile).  The launcher picks it.
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false, bool FULL = false>
+__global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == COLS_EMIT ? 1 : TFFT_COLS_WAVES(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
@@ -892,15 +901,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // A workgroup walks `tiles_per_block` adjacent 16-column tiles.  The twiddles depend on (t, g) only,
     // so they are fetched once; the next tile's data is fetched into registers while the current tile
     // is being transformed (the loads of tile i+1 overlap the LDS exchanges and stores of tile i).
-    if (MODE == COLS_PLAIN && SIGN > 0 && P.gate) {      // the statistics of this image were settled without the spectrum: nothing to redo
-        const SelectState* gs = P.gate + 3 * img;
-        if (gs[0].fast && gs[1].fast && gs[2].fast && gs[0].n_amb <= TFFT_AMB_CAP && gs[1].n_amb <= TFFT_AMB_CAP && gs[2].n_amb <= TFFT_AMB_CAP) return;
-    }
-    // COLS_PLAIN forward with tile_step > 1: tile index i stands for tile i*tile_step of the input and column block i of the output
-    const int ts = (MODE == COLS_PLAIN && SIGN > 0 && P.tile_step > 1) ? P.tile_step : 1;
     const int tile0 = blockIdx.x * P.tiles_per_block;
-    const int toff = ts > 1 ? P.tile_off : 0;
-    const int ntiles = ((P.M + C - 1) / C - toff + ts - 1) / ts;
+    const int ntiles = (P.M + C - 1) / C;
     const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
     // The loads of a tile are UNCONDITIONAL at clamped (always valid) addresses; elements that do not exist (rows >= in_rows, the
     // columns / groups beyond the grid) are zeroed by tile_mask() when the tile is consumed.  Written as `cond ? src[i] : 0` every
@@ -910,32 +912,33 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     const int rows_in_max = P.in_a * (L - 1) + P.in_b * (P.G - 1);            // highest input row any thread of the launch addresses
     const bool in_full = (rows_in_max < P.in_rows) && (P.M % C == 0) && (P.G % (int)blockDim.z == 0);
     auto load_tile = [&](int tile, float2 (&v)[E]) {
-        const int col = imin((tile * ts + toff) * C + c, P.M - 1);
-        const float2* src = in + plane_off + col;
-        const int gc = imin(g, P.G - 1);
+        const int col = imin(tile * C + c, P.M - 1);
+        const float2* src = in + plane_off;       // workgroup-uniform base + a 32-bit element offset per load (a plane holds < 2^27 bins):
+        const int gc = imin(g, P.G - 1);          // one offset register per load instead of a 64-bit address pair
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const int row = imin(P.in_a * (t + m * T) + P.in_b * gc, P.in_rows - 1);
-            v[m] = src[(size_t)row * P.M];
+            v[m] = src[(unsigned)(row * P.M + col)];
         }
     };
     auto tile_mask = [&](int tile, float2 (&v)[E]) {       // workgroup-uniform test first: the final steps never need it
         if (in_full) return;
-        const bool active = ((tile * ts + toff) * C + c < P.M) && (g < P.G);
+        const bool active = (tile * C + c < P.M) && (g < P.G);
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const int row = P.in_a * (t + m * T) + P.in_b * g;
             if (!(active && row < P.in_rows)) v[m] = make_float2(0.f, 0.f);
         }
     };
+    constexpr bool PF = (LOGL <= TFFT_COLS_PF_MAXLOG || MODE == COLS_EMIT) && MODE != COLS_EMBED;      // one tile ahead in registers (EMBED loads no tile: its lists always travel one tile ahead)
     float2 u[E], un[E];
     // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
-    auto load_aw = [&](int tile) -> float2 { const int col = (tile * ts + toff) * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     // the first tile's loads go out before anything else: the tables staged below (each a global -> LDS round trip) ride behind them,
     // and ONE barrier at the end of the prologue covers them all
-    if (MODE != COLS_EMBED) { load_tile(tile0, u); awc = load_aw(tile0); }
+    if (PF) { load_tile(tile0, u); awc = load_aw(tile0); }
     const int out_rows = (MODE == COLS_ROWLIMIT) ? imin(P.out_rows, *P.last_row_dev + 1) : P.out_rows;
     // DC removal: this group's rows of c*A_H staged behind the exchange buffers (read once per tile and output)
     float2* lds_ah = reinterpret_cast<float2*>(tfft_smem) + (size_t)blockDim.z * L * C + (size_t)gl * L;
@@ -990,7 +993,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
     // the bucket offsets of the workgroup's tiles (at most NOFF: the launcher sees to it) sit in LDS: read with lgkmcnt, not vmcnt,
     // and without the branch trees a register array indexed by the tile turned into
     unsigned* lds_eo = reinterpret_cast<unsigned*>(lds_tw + (TWL ? L : 0) + blockDim.z * C) + gl * (NOFF + 2);
-    if (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {
+    if (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT) {
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
         for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
     }
@@ -1026,65 +1029,18 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
         if (conj) nv = cconj(nv);
         return csub(nv, f);
     };
-    // ---- COLS_STAT: k_collect_bracket's per-value work (see there) on this kernel's registers
-    const int st_lin = (gl * T + t) * C + c, st_wave = st_lin >> 6;
-    unsigned* st_wbuf = lds_eo + (blockDim.z - gl) * (NOFF + 2) + st_wave * 256;      // behind the offsets of all groups: 256 staged candidates per wave
-    unsigned* st_wcnt = lds_eo + (blockDim.z - gl) * (NOFF + 2) + ((blockDim.x * blockDim.y * blockDim.z) >> 6) * 256;      // [0] the workgroup's count, [1 + wave] a wave's list base
-    SelectState* st_s = (MODE == COLS_STAT) ? P.st_sel + 3 * img + plane : nullptr;
-    const unsigned st_lo = (MODE == COLS_STAT) ? st_s->lo : 0u, st_span = (MODE == COLS_STAT) ? st_s->hi - st_lo : 0u, st_base = st_lo << 19;
-    const float st_t2lo = (MODE == COLS_STAT) ? st_s->t2_lo : 0.f, st_t2hi = (MODE == COLS_STAT) ? st_s->t2_hi : 0.f;
-    unsigned* st_out = (MODE == COLS_STAT) ? P.st_cand + ((size_t)img * 3 + plane) * P.st_cand_stride : nullptr;
-    float* st_ambo = (MODE == COLS_STAT) ? P.st_amb + ((size_t)img * 3 + plane) * TFFT_AMB_CAP : nullptr;
-    unsigned st_below = 0, st_nstaged = 0, st_capcount = 0;
-    auto st_classify = [&](bool valid, unsigned b) {
-        const unsigned bk = b >> 19;
-        st_below += (valid && bk < st_lo) ? 2u : 0u;
-        const bool cnd = valid && (bk - st_lo) <= st_span;
-        const unsigned long long mk = __ballot(cnd);
-        if (mk) {                       // wave uniform
-            if (cnd) st_wbuf[st_nstaged + wave_rank_of(mk)] = (b - st_base) | 0x80000000u;
-            st_nstaged += (unsigned)__popcll(mk);
-        }
-    };
-    auto st_flush = [&]() {             // wave uniform: the wave's staged candidates go to the plane's list with one global atomic
-        const int lane = st_lin & 63;
-        WaveSync::sync();
-        if (lane == 0) st_wcnt[1 + st_wave] = atomicAdd(&st_s->n_cand, st_nstaged);
-        WaveSync::sync();
-        const unsigned gbase = st_wcnt[1 + st_wave];
-        for (unsigned i = lane; i < st_nstaged; i += 64) st_out[gbase + i] = st_wbuf[i];
-        WaveSync::sync();
-        st_nstaged = 0;
-    };
-    // the mirror bins ((PH-row)%PH, PW-colx) lie at columns > PW/2: inside the annulus only when it reaches beyond PW/2 (tall grids)
-    const bool st_mirror = (MODE == COLS_STAT) && (unsigned long long)(P.st_PW - P.M) * (unsigned long long)(P.st_PW - P.M) <= (unsigned long long)P.st_shi;
-    auto st_cap_elem = [&](int row, int colx, float m2) {
-        // the stored bin (row, colx), 0 < colx < M, stands for the full-grid bins (row, colx) and ((PH-row)%PH, PW-colx): each counts
-        // when it is off the axes and inside the annulus (S:698-700, S:998-1008)
-        unsigned w = 0;
-        if (row != 0 && 2 * row != P.PH) {
-            const unsigned d1 = (unsigned)row * (unsigned)row + (unsigned)colx * (unsigned)colx;
-            w = (d1 >= P.st_slo && d1 <= P.st_shi) ? 1u : 0u;
-            if (st_mirror) {
-                const unsigned ym = (unsigned)(P.PH - row), xm = (unsigned)(P.st_PW - colx);
-                const unsigned d2 = ym * ym + xm * xm;
-                w += (d2 >= P.st_slo && d2 <= P.st_shi) ? 1u : 0u;
-            }
-        }
-        if (!w) return;
-        if (!(m2 < st_t2hi)) st_capcount += w;
-        else if (w && !(m2 < st_t2lo)) {                     // rare: settled once the median is known
-            for (unsigned k = 0; k < w; k++) {
-                const unsigned slot = atomicAdd(&st_s->n_amb, 1u);
-                if (slot < TFFT_AMB_CAP) st_ambo[slot] = m2;
-            }
-        }
-    };
     if (MODE == COLS_EMBED) em_entries(tile0, enC, true);
-    if (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ) em_entries(tile0, enC, false);
+    if (PF && (MODE == COLS_EMIT || MODE == COLS_READ)) em_entries(tile0, enC, false);
     for (int tile = tile0; tile < tile1; tile++) {
-        if (MODE != COLS_EMBED && tile + 1 < tile1 && has_bins(tile + 1)) { load_tile(tile + 1, un); awn = load_aw(tile + 1); }
-        if (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
+        if (!PF && MODE != COLS_EMBED) {      // no prefetch: this tile's loads and list entries now; another resident workgroup covers the wait
+            if (!has_bins(tile)) continue;
+            load_tile(tile, u); awc = load_aw(tile);
+            if (MODE == COLS_EMIT || MODE == COLS_READ) em_entries(tile, enC, false);
+        }
+        // the next tile's loads ALWAYS go out (a load inside a branch cannot be counted by s_waitcnt: every later wait would drain the
+        // queue): past the last tile, or when the next tile has no bins to read, this tile is fetched again (cache resident, never used)
+        if (PF) { const int nt = (tile + 1 < tile1 && has_bins(tile + 1)) ? tile + 1 : tile; load_tile(nt, un); awn = load_aw(nt); }
+        if (PF && (MODE == COLS_EMIT || MODE == COLS_READ)) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
         if (MODE == COLS_EMBED) {
             // the tile of F' - F: zeros but for the bins of the list (S:712-732 per bin); a tile without bins is stored as zeros.
             // The values of tile+1's bins and the entries of tile+2 are fetched now (see em_* above the loop).
@@ -1116,16 +1072,16 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                 else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
             }
             const int col = tile * C + c;
-            if ((col < P.M) && (g < P.G)) {
-                float2* dst = out + plane_off + col;
+            if (FULL || ((col < P.M) && (g < P.G))) {
+                float2* dst = out + plane_off;
 #pragma unroll
                 for (int m = 0; m < E; m++) {
                     const int k = t + m * T;
                     const int row = P.out_a * k + P.out_b * g;
-                    if (row < out_rows) {
+                    if (FULL || row < out_rows) {
                         float2 v = hb ? u[m] : make_float2(0.f, 0.f);
                         if (TW && hb) v = cmul(v, lds_wo[k]);
-                        dst[(size_t)row * P.M] = v;
+                        dst[(unsigned)(row * P.M + col)] = v;
                     }
                 }
             }
@@ -1133,7 +1089,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             for (int i = 0; i < NE; i++) enC[i] = enN[i];
             continue;
         }
-        if (!has_bins(tile)) {
+        if (PF && !has_bins(tile)) {
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
             awc = awn;
@@ -1157,55 +1113,59 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             // the tile (that was 0.056 ms of the 0.50 ms launch): the tile's 16 column factors go to LDS beside the row factors
             if (DC && t == 0) lds_aw[c] = awc;
             lds_barrier();
-            if (g < P.G) {
+            if (FULL || g < P.G) {
                 // the tile's entries travelled with its loads (NE per thread in registers; a longer bucket fetches the rest in place)
                 unsigned e0, e1;
                 em_range(tile, e0, e1);
                 uint8_t* bo = P.rd_bits + (size_t)img * P.rd_n;
-                auto read_one = [&](const TileBin tb) {
+                auto bit_of = [&](const TileBin tb) -> uint8_t {       // read_bit_from_bin S:734-746 for a fixed alpha in (0, pi), no jitter: Im >= 0
                     float2 v = lds[lay.idx(tb.k, tb.c)];
                     if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
-                    if (tb.conj) v = cconj(v);
-                    bo[tb.bit] = (uint8_t)(P.rd_generic ? read_bit_value(v, *P.rd_ep, plane, P.rd_jitter, tb.bit) : (v.y >= 0.0f ? 1 : 0));
+                    return (uint8_t)((tb.conj ? -v.y : v.y) >= 0.0f ? 1 : 0);
                 };
+                // stores without a predicate (see FULL): a lane without an entry writes its byte to the context's scratch line instead
 #pragma unroll
-                for (int i = 0; i < NE; i++)
-                    if (enC[i].live) read_one(enC[i].tb);
-                for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) read_one(P.rd_bins[e]);
+                for (int i = 0; i < NE; i++) {
+                    const TileBin tb = enC[i].tb;
+                    uint8_t* dst = enC[i].live ? bo + tb.bit : P.trash + em_tid;
+                    *dst = bit_of(tb);
+                }
+                for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) { const TileBin tb = P.rd_bins[e]; bo[tb.bit] = bit_of(tb); }
             }
             lds_barrier();            // before the next tile's exchanges overwrite the parked values
+            if (PF) {
 #pragma unroll
-            for (int m = 0; m < E; m++) u[m] = un[m];
-            awc = awn;
+                for (int m = 0; m < E; m++) u[m] = un[m];
+                awc = awn;
 #pragma unroll
-            for (int i = 0; i < NE; i++) enC[i] = enN[i];
+                for (int i = 0; i < NE; i++) enC[i] = enN[i];
+            }
             continue;
         }
-        const int col = (tile * ts + toff) * C + c;
-        if (MODE == COLS_STAT) {
-            // nothing is stored: the values are classified below, once the tile is parked in LDS
-        } else if ((col < P.M) && (g < P.G)) {
+        const int col = tile * C + c;
+        if (FULL || ((col < P.M) && (g < P.G))) {
             const int ocol = tile * C + c;
-            const int oM = ts > 1 ? P.out_M : P.M;
-            float2* dst = out + (ts > 1 ? (size_t)img * P.out_img_stride + (size_t)plane * P.out_plane_stride : plane_off) + ocol;
+            const int oM = P.M;
+            float2* dst = out + plane_off;
+            float* dst_m2 = reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride;
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 const int k = t + m * T;
                 const int row = P.out_a * k + P.out_b * g;
-                if (row < out_rows) {
+                if (FULL || row < out_rows) {
                     float2 v = u[m];
                     if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
                     if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
                         if (P.em_m2 == 1) {                  // asked for, nothing at all)
-                            reinterpret_cast<float*>(out + (size_t)img * P.img_stride)[(size_t)plane * P.plane_stride + (size_t)row * P.M + col] = fmaf(v.x, v.x, v.y * v.y);
-                            if (col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
+                            dst_m2[(unsigned)(row * P.M + col)] = fmaf(v.x, v.x, v.y * v.y);
+                            if (tile == 0 && c == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;      // the packed column 0: tile 0 only
                         }
-                    } else dst[(size_t)row * oM] = v;
+                    } else dst[(unsigned)(row * oM + ocol)] = v;
                 }
             }
         }
-        if (MODE == COLS_EMIT || MODE == COLS_STAT) {
+        if (MODE == COLS_EMIT) {
             // park the tile (as COLS_READ does) and write the values of the listed bins, DC term included, into the list the first
             // inverse step embeds from: em_fl[entry index], coalesced
             lds_barrier();            // the last gather of fft_block has been consumed by every thread
@@ -1213,36 +1173,17 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             if (DC && t == 0) lds_aw[c] = awc;
             lds_barrier();
-            if (MODE == COLS_STAT) {
-                // the bracket pass of the statistics (k_collect_bracket's classify / cap_elem) on the parked tile: one value = one stored
-                // bin (row, col) of weight 2; the packed column 0 is left to k_col0_stats.  A rolled loop over LDS: unrolled over the
-                // registers it took the kernel to 256 VGPRs and 86 spilled SGPRs
-                const bool live = (col < P.M) && (g < P.G);
-#pragma unroll 2
-                for (int m = 0; m < E; m++) {
-                    const int k = t + m * T;
-                    const int row = P.out_a * k + P.out_b * g;
-                    float2 v = lds[lay.idx(k, c)];
-                    if (DC) v = cadd(v, cmul(lds_ah[k], awc));
-                    if (live && col == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;
-                    const float m2 = fmaf(v.x, v.x, v.y * v.y);
-                    st_classify(live && col != 0, __float_as_uint(m2));
-                    if (P.st_cap && live && col != 0) st_cap_elem(row, col, m2);
-                    if ((m & 1) && st_nstaged > 128) st_flush();        // at most 2 * 64 more before the next check: 256 slots
-                }
-            }
             {
                 unsigned e0, e1;
                 em_range(tile, e0, e1);
                 float2* fl = P.em_fl + (size_t)img * P.em_n;
 #pragma unroll
-                for (int i = 0; i < NE; i++) {
+                for (int i = 0; i < NE; i++) {      // no predicate on the store (see FULL): lanes without an entry write to the context's scratch line
                     const TileBin tb = enC[i].tb;
-                    if (enC[i].live) {
-                        float2 v = lds[lay.idx(tb.k, tb.c)];
-                        if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
-                        fl[e0 + (unsigned)(em_tid + i * em_nthr)] = v;
-                    }
+                    float2 v = lds[lay.idx(tb.k, tb.c)];
+                    if (DC) v = cadd(v, cmul(lds_ah[tb.k], lds_aw[tb.c]));
+                    float2* dst = enC[i].live ? fl + (e0 + (unsigned)(em_tid + i * em_nthr)) : reinterpret_cast<float2*>(P.trash) + em_tid;
+                    *dst = v;
                 }
                 for (unsigned e = e0 + (unsigned)(em_tid + NE * em_nthr); e < e1; e += em_nthr) {
                     const TileBin tb = P.rd_bins[e];
@@ -1252,24 +1193,15 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(TFFT_COL
                 }
             }
             lds_barrier();            // before the next tile's exchanges overwrite the parked values
+            if (PF) {
 #pragma unroll
-            for (int i = 0; i < NE; i++) enC[i] = enN[i];
+                for (int i = 0; i < NE; i++) enC[i] = enN[i];
+            }
         }
+        if (PF) {
 #pragma unroll
-        for (int m = 0; m < E; m++) u[m] = un[m];
-        awc = awn;
-    }
-    if (MODE == COLS_STAT) {
-        if (st_nstaged) st_flush();
-        if (st_below) atomicAdd(&st_s->below, (unsigned long long)st_below);
-        if (P.st_cap) {          // one count per workgroup
-            lds_barrier();
-            if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) st_wcnt[0] = 0;
-            lds_barrier();
-            if (st_capcount) atomicAdd(&st_wcnt[0], st_capcount);
-            lds_barrier();
-            if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0 && st_wcnt[0])
-                atomicAdd(&P.st_partial[((size_t)img * 3 + plane) * TFFT_STAT_MAX_BLOCKS + ((blockIdx.y * gridDim.x + blockIdx.x) % TFFT_STAT_MAX_BLOCKS)], st_wcnt[0]);
+            for (int m = 0; m < E; m++) u[m] = un[m];
+            awc = awn;
         }
     }
 }
@@ -1979,9 +1911,9 @@ __global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __rest
         if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
 }
 
-// statistics inside the last forward column step (COLS_STAT): what that kernel leaves to do.
-// (a) the packed column 0: F[y][0] and F[y][M] (unpack_col0), one value of weight 1 each, classified like k_collect_bracket does;
-//     neither column belongs to the annulus count (x = 0 and 2x = PW are excluded, S:698-700)
+// |F|^2 planes (batched delta embeds): the packed column 0 travels beside the plane as complex values -- F[y][0] and F[y][M]
+// (unpack_col0), one value of weight 1 each, classified like k_collect_bracket does; neither column belongs to the annulus count
+// (x = 0 and 2x = PW are excluded, S:698-700)
 __global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectState* __restrict__ st, unsigned* __restrict__ cand, size_t cand_stride,
                              int with_hist) {
     SelectState* s = st + (size_t)blockIdx.z * 3 + blockIdx.y;
@@ -2006,23 +1938,6 @@ __global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectStat
     }
     if (below) atomicAdd(&s->below, (unsigned long long)below);
 }
-// (b) the level-2 histogram of the candidates (k_collect_bracket builds it while it stages them)
-__global__ void k_hist_cand2(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
-    SelectState* s = sel_of(st);
-    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const unsigned n = s->n_cand;
-    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned c = in[i], v = c & 0x7FFFFFFFu;
-        atomicAdd(&hist[(v >> 11) & 1023u], (c >> 31) ? 2u : 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
-        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
-}
-
 // ---- compact pipeline (planes up to 2^24 bins): the three launches after the bracket pass in one, the six fallback launches
 // in one.  A single image spends its time in the GPU-side latency of dependent launches (~6.7 us each: the statistics were 16 of
 // the ~35 of a 1080p round trip), not in the kernels.
@@ -2550,28 +2465,32 @@ hipError_t launch_rows_inv(const float2* in, uint8_t* rgb, const float2* tw_pw, 
     return hipSuccess;
 }
 
-template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false>
+template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false, bool FULL = false>
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
+    if constexpr (!FULL && LOGL >= 6 && MODE != COLS_ROWLIMIT) {
+        // every output element exists: the variant whose stores carry no predicate (ROWLIMIT cuts rows by definition)
+        const int rows_out_max = P.out_a * (L - 1) + P.out_b * (P.G - 1);
+        if (rows_out_max < P.out_rows && P.M % C == 0 && P.G % gpb == 0)
+            return launch_cols_t<LOGL, SIGN, MODE, DC, TW, true>(in, out, tw, P, n_planes, s);
+    }
     const size_t lds0 = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
                        (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0);
     const int ntiles = (P.M + C - 1) / C;
     int tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     ColParams Q = P;
-    constexpr bool BUCKETS = (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT);
+    constexpr bool BUCKETS = (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT);
     if (BUCKETS) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
         if (tpb > 16) tpb = 16;
         Q.tiles_per_block = tpb;
     }
-    const size_t nwaves = ((size_t)C * T * gpb + 63) / 64;
-    const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
-                       (MODE == COLS_STAT ? (nwaves * 257 + 1) * sizeof(unsigned) : 0);
+    const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0);
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
-    auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW>;
+    auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW, FULL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -2586,9 +2505,8 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
     if (P.em_on && !P.em_fl) return hipErrorInvalidValue;
+    if (P.rd_bins && !P.trash) return hipErrorInvalidValue;       // the bucket modes redirect the stores of idle lanes to the context's scratch line
     if (P.em_m2 && sign > 0 && (!P.em_on || !P.st_col0)) return hipErrorInvalidValue;      // (the inverse step ignores it)
-    if (P.st_sel && (!P.em_on || sign < 0 || logl > 9 || !P.st_cand || !P.st_col0 || (P.st_cap && (!P.st_partial || !P.st_amb)))) return hipErrorInvalidValue;
-    if ((P.tile_step > 1 || P.gate) && (sign < 0 || P.rd_bins || P.last_row_dev || P.tw_out)) return hipErrorInvalidValue;      // plain final forward step only
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
              : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
@@ -2601,7 +2519,7 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
 #define F(n)                                                                            \
     return sign < 0 ? (P.em_on ? GE(n) : P.dc_ah ? GI(n, true) : GI(n, false)) \
          : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
-         : (P.em_on && P.st_sel) ? G(n, COLS_STAT) : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
+         : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
 #undef G
@@ -2765,54 +2683,6 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
             hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
             if (e != hipSuccess) return e;
         }
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s) {
-    hipLaunchKernelGGL(k_skew_bracket, dim3(3 * n_images), dim3(64), 0, s, st, skew);
-    return hipGetLastError();
-}
-// ---- statistics inside the last forward column step (COLS_STAT): the launches around it.
-// (1) bracket guess from a sample of the column tiles (a narrow spectrum of Ms columns written by the plain step with tile_step)
-hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t mini_img_stride, int n_images, SelectState* st, const CapParams* cap,
-                             unsigned* partial, int col0_packed, hipStream_t s) {
-    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
-    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
-    hipError_t e = hipMemsetAsync(partial, 0, (size_t)n_images * (3 * TFFT_STAT_MAX_BLOCKS + 1) * sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
-    int step = (int)(((long long)PH * Ms) / 65536); if (step < 1) step = 1; if (step > 64) step = 64;       // ~65 k sampled values per plane
-    unsigned nbs = (unsigned)((PH + step - 1) / step);
-    { unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < 32u ? want : 32u; }
-    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed, (const float2*)nullptr);
-    hipLaunchKernelGGL(k_select_guess, dim3(3 * n_images), dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
-    return hipGetLastError();
-}
-// (2) after the COLS_STAT step: the packed column 0, the candidates' level-2 histogram, the verified select
-hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s) {
-    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
-    const dim3 gs(3 * n_images);
-    hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0, PH, st, cand, cand_stride, 0);
-    unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
-    if (nbh < 16) nbh = 16;
-    if (nbh > 256) nbh = 256;
-    hipLaunchKernelGGL(k_hist_cand2, dim3(nbh, 3, n_images), dim3(256), 1024 * sizeof(unsigned), s, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
-    hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
-    hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
-    return hipGetLastError();
-}
-// (3) the planes the fast path could not settle (their spectrum has been produced by the gated plain step in between), the capacity
-hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st, float* med_out, const CapParams* cap,
-                              unsigned* partial, float* amb, unsigned long long* usable, hipStream_t s) {
-    const int M = PW >> 1;
-    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
-    const unsigned fin_lds = (4096 + 256 + 16) * sizeof(unsigned) + 4 * sizeof(unsigned long long);
-    hipLaunchKernelGGL(k_median_fallback, dim3(3 * n_images), dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, 0, (const float2*)nullptr);
-    if (cap) {
-        unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;
-        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)TFFT_STAT_MAX_BLOCKS, amb, usable, flag,
-                           spec, *cap, 1, 0);
     }
     return hipGetLastError();
 }

@@ -622,7 +622,7 @@ def _ctx_with_env(env, *a, **kw):
                 os.environ[k] = v
 
 
-def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, center=False, sort=True, lsb_frac=0.01, with_oracle=True, tile_stats=True):
+def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, center=False, sort=True, lsb_frac=0.01, with_oracle=True):
     """Batched embedding as the default pipeline runs it -- stego = cover + IFFT(F' - F), the first inverse column step building its
     tiles from the bucketed bins (S:712-732 per bin, S:1099-1102 by linearity) -- against (a) the fp64 reference's stego image,
     (b) the write-F'-then-invert pipeline (TFFT_EMBED_DELTA=0), and (c) the reference's reading of OUR stego image."""
@@ -654,9 +654,6 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
             raw = bufs.get(rb).copy()
         ctx.close()
     (sd, ud), (s0, u0) = out["1"], out["0"]
-    # TFFT_STATS_TILE=1 (optional, off by default): the statistics of the delta pipeline inside the last forward column step, no stored
-    # spectrum: same capacities, same stego bytes; and with every bracket moved off the median (test hook) its fast path fails and the
-    # gated fallback must return them too
     # embedding in place (output buffer = cover buffer): the last kernel reads the cover's bytes it is about to overwrite
     ctx = B.Context(w, h, slots=max(1, nimg - 1), lib=lib)
     if idx is not None:
@@ -669,8 +666,7 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     # TFFT_STATS_SKEW (test hook): every bracket moved off the median -- the fast path of the statistics fails and their fallbacks
     # (on the |F|^2 planes the delta pipeline stores) must return the same capacities
     # ... TFFT_STATS_M2=0 / TFFT_STATS_ASYNC=0: the statistics on the complex spectrum, in line (the A/B forms of the default)
-    for env in (({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}, {"TFFT_STATS_TILE": "1"}, {"TFFT_STATS_TILE": "1", "TFFT_STATS_TILE_SKEW": "5"})
-                if tile_stats else ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"})):
+    for env in ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}):
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
             ctx.set_bit_index(idx)

@@ -316,9 +316,9 @@ def test_tile_resident_extraction_over_the_column_plans(emu, orc, wh):
     assert set(np.unique(res[0])) <= {0, 1}
 
 
-@pytest.mark.parametrize("case", [dict(w=40, h=24, n_bits=150, tile_stats=False), dict(w=40, h=300, n_bits=300, rmax=0.95), dict(w=2040, h=130, n_bits=300, nimg=1),
-                                  dict(w=100, h=64, n_bits=200, center=True, sort=False, tile_stats=False),
-                                  dict(w=64, h=64, n_bits=1500, rmax=0.95, nimg=3, tile_stats=False)])      # the last: buckets longer than the prefetch depth
+@pytest.mark.parametrize("case", [dict(w=40, h=24, n_bits=150), dict(w=40, h=300, n_bits=300, rmax=0.95), dict(w=2040, h=130, n_bits=300, nimg=1),
+                                  dict(w=100, h=64, n_bits=200, center=True, sort=False),
+                                  dict(w=64, h=64, n_bits=1500, rmax=0.95, nimg=3)])      # the last: buckets longer than the prefetch depth
 def test_delta_embedding_over_the_column_plans(emu, orc, case):
     """stego = cover + IFFT(F' - F) with tiles built from the bucketed bins: direct, two-step (mirror half included) and fused plans"""
     lsb = 0.05 if case["w"] * case["h"] < 4096 else 0.01
