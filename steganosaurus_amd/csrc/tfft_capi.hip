@@ -167,7 +167,7 @@ ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi, int n) {
     ColPlan p;
     p.fused_fwd = false;
     if (c->fuse && c->cols_force_log_n1 < 0 && l >= 7 &&
-        ((PWi == 2048 && l - 3 <= 10) || (PWi == 4096 && l - 3 <= 9 && (c->fuse_wide >= 2 || (c->fuse_wide == 1 && n >= 2))))) {
+        ((PWi == 2048 && l - 3 <= 9) || (PWi == 4096 && l - 3 <= 9 && (c->fuse_wide >= 2 || (c->fuse_wide == 1 && n >= 2))))) {
         // rows + first column step in one kernel (k_rowcol_fwd): PH = 8 * N2.  2048 wide: one wave per row; 4096 wide: two waves
         // per row, 1024-thread workgroups, for launches of two or more images (TFFT_FUSE_WIDE=0: never, 2: always)
         p.direct = false; p.log_n1 = 3; p.log_n2 = l - 3; p.fused_fwd = true;
@@ -178,7 +178,7 @@ ColPlan plan_cols(const tfft_ctx* c, int PH, int PWi, int n) {
     int l1 = (c->cols_force_log_n1 >= 0) ? c->cols_force_log_n1 : l / 2;
     if (l1 < 1) l1 = 1;
     if (l1 > l - 1) l1 = l - 1;
-    if (l - l1 > 10) l1 = l - 10;
+    if (l - l1 > 9) l1 = l - 9;
     p.log_n1 = l1; p.log_n2 = l - l1;
     return p;
 }

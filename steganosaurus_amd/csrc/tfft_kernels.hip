@@ -29,16 +29,22 @@
 #ifndef TFFT_WAVES_PER_EU
 #define TFFT_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
-// column kernels of 16 elements per thread: occupancy floor handed to the register allocator.  Measured (round 2, A/B on one
-// box): 2 (<= 256 registers, two workgroups per CU) buys NOTHING where it fits (final forward step 0.653 vs 0.646 ms) and
-// doubles the run time of the variants that then spill to scratch (output-twiddle steps 0.94 / 1.19 vs 0.50 / 0.64 ms), so 1.
+// Column kernels: occupancy floor handed to the register allocator (waves per SIMD) and whether the next tile is prefetched into
+// registers.  Round 3 (same-box A/B, gpurun_out/r3e): from L = 256 on the kernels hold NO tile ahead (32 VGPRs less) and fit 4 waves per
+// SIMD instead -- two 512-thread workgroups per CU at L = 512, four 256-thread ones at L = 256 -- so that one workgroup's loads and LDS
+// exchanges run under another one's arithmetic: tile-resident extraction 0.542 -> 0.387 ms per 8 x 4K launch, 0.348 -> 0.321 per
+// 32 x 1080p.  (Round 2 had measured "two workgroups per CU buy nothing" -- on kernels whose prefetch never overlapped anything
+// because their predicated loads defeated s_waitcnt's counting, see load_tile.)  The variants with predicated stores (!FULL: the
+// last inverse step, the row-limited extraction of small chunks) need more registers and keep a floor of two.
 #ifndef TFFT_COLS_WAVES
-#define TFFT_COLS_WAVES(logl) 1
+#define TFFT_COLS_WAVES(logl) ((logl) >= 8 ? 4 : 1)
 #endif
-// column kernels of length <= 2^this fetch the next tile into registers while the current one is transformed; longer ones do not
-// prefetch and rely on a second resident workgroup instead (see k_fft_cols)
+// column kernels of length <= 2^this fetch the next tile into registers while the current one is transformed
 #ifndef TFFT_COLS_PF_MAXLOG
-#define TFFT_COLS_PF_MAXLOG 10
+#define TFFT_COLS_PF_MAXLOG 7
+#endif
+#ifndef TFFT_COLS_PFEMIT
+#define TFFT_COLS_PFEMIT 0      // 1: COLS_EMIT keeps the register prefetch and one wave per SIMD whatever the length (A/B)
 #endif
 #ifndef TFFT_ROWS_LAZY_LOG
 #define TFFT_ROWS_LAZY_LOG 11
@@ -862,6 +868,12 @@ k_rows_inv(const float2* __restrict__ in, uint8_t* __restrict__ rgb, const float
 // The column loop of fft2d S:362-365.
 //   grid (ceil(M/16), ceil(G/GPB), n_planes)   block (16, T, GPB)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned opaque_u32(unsigned v) {
+#if defined(__HIPCC__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 constexpr int cols_threads(int logl) { return imax(256, 16 * ((1 << logl) / elems_for(1 << logl))); }
 __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, int p, const float* __restrict__ jitter, uint64_t j);   // defined with k_read
 
@@ -888,7 +900,7 @@ __device__ __forceinline__ unsigned frame_bit(const uint8_t* __restrict__ header
 //       behind an exec-mask branch may or may not have been issued, so s_waitcnt cannot count past it: the wait for the prefetched
 //       tile that follows then also waits for the stores just issued (their whole latency, every tile).  The launcher picks it.
 template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = false, bool FULL = false>
-__global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == COLS_EMIT ? 1 : TFFT_COLS_WAVES(LOGL)) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
+__global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE == COLS_EMIT && TFFT_COLS_PFEMIT) ? 1 : (FULL ? TFFT_COLS_WAVES(LOGL) : imin(2, TFFT_COLS_WAVES(LOGL)))) k_fft_cols(const float2* in, float2* out, const float2* __restrict__ tw,
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
@@ -911,14 +923,35 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == 
     // also waited for the tile prefetched a moment earlier -- the one-tile-ahead prefetch never overlapped anything (rounds 1-2).
     const int rows_in_max = P.in_a * (L - 1) + P.in_b * (P.G - 1);            // highest input row any thread of the launch addresses
     const bool in_full = (rows_in_max < P.in_rows) && (P.M % C == 0) && (P.G % (int)blockDim.z == 0);
+    // (opaque_u32: the value, made opaque to the optimiser inside the tile loop -- without it the per-thread part of every address
+    //  is loop invariant and gets hoisted as sixteen 64-bit pairs all the same)
+    // Addressing.  Element m of a thread sits m * (a * T * M) bins after its element 0 -- a workgroup-uniform stride -- and a tile
+    // 16 bins after the previous one, so an access is (uniform 64-bit base of (tile, m), in SGPRs) + (ONE 32-bit byte offset per
+    // thread), the form global_load / global_store take directly.  Left to the compiler, every access had its own loop-invariant
+    // 64-bit address: 16 pairs for the loads, 16 per store flavour -- hoisted out of the tile loop and, at four waves per SIMD,
+    // spilled (COLS_EMIT: 328 bytes of scratch).  A plane has < 2^27 bins, so byte offsets fit 32 bits.
+    const unsigned voff_in = (unsigned)((P.in_a * t + P.in_b * g) * P.M + c) * 8u;
+    const size_t stride_in = (size_t)P.in_a * T * P.M * sizeof(float2);
+    const char* in_bytes = reinterpret_cast<const char*>(in + plane_off);
+    const unsigned voff_out = (unsigned)((P.out_a * t + P.out_b * g) * P.M + c) * 8u;
+    const size_t stride_out = (size_t)P.out_a * T * P.M * sizeof(float2);
+    char* out_bytes = reinterpret_cast<char*>(out + plane_off);
+    char* m2_bytes = reinterpret_cast<char*>(reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride);      // COLS_EMIT: the |F|^2 plane
     auto load_tile = [&](int tile, float2 (&v)[E]) {
-        const int col = imin(tile * C + c, P.M - 1);
-        const float2* src = in + plane_off;       // workgroup-uniform base + a 32-bit element offset per load (a plane holds < 2^27 bins):
-        const int gc = imin(g, P.G - 1);          // one offset register per load instead of a 64-bit address pair
+        if (in_full) {
+            const char* tb = in_bytes + (size_t)tile * (C * sizeof(float2));
+            const unsigned vo = opaque_u32(voff_in);
 #pragma unroll
-        for (int m = 0; m < E; m++) {
-            const int row = imin(P.in_a * (t + m * T) + P.in_b * gc, P.in_rows - 1);
-            v[m] = src[(unsigned)(row * P.M + col)];
+            for (int m = 0; m < E; m++) v[m] = *reinterpret_cast<const float2*>(tb + m * stride_in + vo);
+        } else {
+            const int col = imin(tile * C + c, P.M - 1);
+            const float2* src = in + plane_off;
+            const int gc = imin(g, P.G - 1), to = (int)opaque_u32((unsigned)t);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const int row = imin(P.in_a * (to + m * T) + P.in_b * gc, P.in_rows - 1);
+                v[m] = src[(unsigned)(row * P.M + col)];
+            }
         }
     };
     auto tile_mask = [&](int tile, float2 (&v)[E]) {       // workgroup-uniform test first: the final steps never need it
@@ -930,7 +963,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == 
             if (!(active && row < P.in_rows)) v[m] = make_float2(0.f, 0.f);
         }
     };
-    constexpr bool PF = (LOGL <= TFFT_COLS_PF_MAXLOG || MODE == COLS_EMIT) && MODE != COLS_EMBED;      // one tile ahead in registers (EMBED loads no tile: its lists always travel one tile ahead)
+    constexpr bool PF = (LOGL <= TFFT_COLS_PF_MAXLOG || (MODE == COLS_EMIT && TFFT_COLS_PFEMIT)) && MODE != COLS_EMBED;      // one tile ahead in registers (EMBED loads no tile: its lists always travel one tile ahead)
     float2 u[E], un[E];
     // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
@@ -985,7 +1018,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == 
 #ifndef TFFT_EMBED_NE9
 #define TFFT_EMBED_NE9 2
 #endif
-    constexpr int NE = (LOGL >= 9) ? (MODE == COLS_EMBED ? TFFT_EMBED_NE9 : 4) : 2;
+    constexpr int NE = (LOGL >= 9) ? (MODE == COLS_EMBED ? (LOGL == 9 ? TFFT_EMBED_NE9 : 2) : 4) : 2;
     struct EmEntry { TileBin tb; float2 f; unsigned bit, live; };   // bucket entry, the stored value of its bin (conjugate of the bin when
                                                                     // tb.conj) and its stream bit (2: beyond the end of the stream)
     EmEntry enC[NE], enN[NE];
@@ -1072,13 +1105,23 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == 
                 else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
             }
             const int col = tile * C + c;
-            if (FULL || ((col < P.M) && (g < P.G))) {
-                float2* dst = out + plane_off;
+            if (FULL) {
+                char* ob = out_bytes + (size_t)tile * (C * sizeof(float2));
+                const unsigned vo = opaque_u32(voff_out);
 #pragma unroll
                 for (int m = 0; m < E; m++) {
-                    const int k = t + m * T;
+                    float2 v = hb ? u[m] : make_float2(0.f, 0.f);
+                    if (TW && hb) v = cmul(v, lds_wo[t + m * T]);
+                    *reinterpret_cast<float2*>(ob + m * stride_out + vo) = v;
+                }
+            } else if ((col < P.M) && (g < P.G)) {
+                float2* dst = out + plane_off;
+                const int to = (int)opaque_u32((unsigned)t);
+#pragma unroll
+                for (int m = 0; m < E; m++) {
+                    const int k = to + m * T;
                     const int row = P.out_a * k + P.out_b * g;
-                    if (FULL || row < out_rows) {
+                    if (row < out_rows) {
                         float2 v = hb ? u[m] : make_float2(0.f, 0.f);
                         if (TW && hb) v = cmul(v, lds_wo[k]);
                         dst[(unsigned)(row * P.M + col)] = v;
@@ -1143,26 +1186,44 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU(MODE == 
             continue;
         }
         const int col = tile * C + c;
-        if (FULL || ((col < P.M) && (g < P.G))) {
-            const int ocol = tile * C + c;
-            const int oM = P.M;
-            float2* dst = out + plane_off;
-            float* dst_m2 = reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride;
+        if (FULL) {
+            char* ob = out_bytes + (size_t)tile * (C * sizeof(float2));
+            char* mb = m2_bytes + (size_t)tile * (C * sizeof(float));
+            const unsigned vo = opaque_u32(voff_out);
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const int k = t + m * T;
+                float2 v = u[m];
+                if (TW) v = cmul(v, lds_wo[t + m * T]);
+                if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[t + m * T], awc));      // last forward step: the rank-1 term comes back
+                if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
+                    if (P.em_m2 == 1) *reinterpret_cast<float*>(mb + m * (stride_out >> 1) + (vo >> 1)) = fmaf(v.x, v.x, v.y * v.y);      // asked for, nothing at all)
+                } else *reinterpret_cast<float2*>(ob + m * stride_out + vo) = v;
+            }
+        } else if ((col < P.M) && (g < P.G)) {
+            float2* dst = out + plane_off;
+            float* dst_m2 = reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride;
+            const int to = (int)opaque_u32((unsigned)t);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const int k = to + m * T;
                 const int row = P.out_a * k + P.out_b * g;
-                if (FULL || row < out_rows) {
+                if (row < out_rows) {
                     float2 v = u[m];
                     if (TW) v = cmul(v, lds_wo[k]);
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
-                    if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
-                        if (P.em_m2 == 1) {                  // asked for, nothing at all)
-                            dst_m2[(unsigned)(row * P.M + col)] = fmaf(v.x, v.x, v.y * v.y);
-                            if (tile == 0 && c == 0) P.st_col0[((size_t)img * 3 + plane) * P.PH + row] = v;      // the packed column 0: tile 0 only
-                        }
-                    } else dst[(unsigned)(row * oM + ocol)] = v;
+                    if (MODE == COLS_EMIT && P.em_m2) {
+                        if (P.em_m2 == 1) dst_m2[(unsigned)(row * P.M + col)] = fmaf(v.x, v.x, v.y * v.y);
+                    } else dst[(unsigned)(row * P.M + col)] = v;
                 }
+            }
+        }
+        if (MODE == COLS_EMIT && P.em_m2 == 1 && tile == 0 && c == 0 && g < P.G) {      // the packed column 0 (its two real spectra cannot be told
+            float2* col0 = P.st_col0 + ((size_t)img * 3 + plane) * P.PH;                  // apart from magnitudes) travels beside the |F|^2 plane
+            const int to = (int)opaque_u32((unsigned)t);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const int row = P.out_a * (to + m * T) + P.out_b * g;
+                if (row < out_rows) col0[(unsigned)row] = (DC && SIGN > 0) ? cadd(u[m], cmul(lds_ah[to + m * T], awc)) : u[m];
             }
         }
         if (MODE == COLS_EMIT) {
@@ -2500,7 +2561,7 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
 }
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
                        int n_planes, hipStream_t s) {
-    if (logl > 10) return hipErrorInvalidValue;     // L*16*8 B must fit the 160 KiB LDS
+    if (logl > 9) return hipErrorInvalidValue;      // 512 x 16 x 8 B tiles: two workgroups per CU; plan_cols never asks for more
     if ((P.last_row_dev || (P.rd_bins && !P.em_on)) && sign < 0) return hipErrorInvalidValue;      // both variants exist for the forward direction only
     if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
@@ -2508,17 +2569,17 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (P.rd_bins && !P.trash) return hipErrorInvalidValue;       // the bucket modes redirect the stores of idle lanes to the context's scratch line
     if (P.em_m2 && sign > 0 && (!P.em_on || !P.st_col0)) return hipErrorInvalidValue;      // (the inverse step ignores it)
 #define G(n, MODE)                                                                      \
-    (P.dc_ah ? launch_cols_t<(n <= 10 ? n : 10), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
-             : launch_cols_t<(n <= 10 ? n : 10), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
+    (P.dc_ah ? launch_cols_t<(n <= 9 ? n : 9), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
+             : launch_cols_t<(n <= 9 ? n : 9), +1, MODE, false>(in, out, tw_ph, P, n_planes, s))
 #define GI(n, DCF)                                                                      \
-    (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, true>(in, out, tw_ph, P, n_planes, s) \
-              : launch_cols_t<(n <= 10 ? n : 10), -1, COLS_PLAIN, DCF, false>(in, out, tw_ph, P, n_planes, s))
+    (P.tw_out ? launch_cols_t<(n <= 9 ? n : 9), -1, COLS_PLAIN, DCF, true>(in, out, tw_ph, P, n_planes, s) \
+              : launch_cols_t<(n <= 9 ? n : 9), -1, COLS_PLAIN, DCF, false>(in, out, tw_ph, P, n_planes, s))
 #define GE(n)                                                                      \
-    (P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), -1, COLS_EMBED, false, true>(in, out, tw_ph, P, n_planes, s) \
-              : launch_cols_t<(n <= 10 ? n : 10), -1, COLS_EMBED, false, false>(in, out, tw_ph, P, n_planes, s))
+    (P.tw_out ? launch_cols_t<(n <= 9 ? n : 9), -1, COLS_EMBED, false, true>(in, out, tw_ph, P, n_planes, s) \
+              : launch_cols_t<(n <= 9 ? n : 9), -1, COLS_EMBED, false, false>(in, out, tw_ph, P, n_planes, s))
 #define F(n)                                                                            \
     return sign < 0 ? (P.em_on ? GE(n) : P.dc_ah ? GI(n, true) : GI(n, false)) \
-         : P.tw_out ? launch_cols_t<(n <= 10 ? n : 10), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
+         : P.tw_out ? launch_cols_t<(n <= 9 ? n : 9), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
          : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
