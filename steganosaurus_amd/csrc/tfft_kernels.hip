@@ -1013,10 +1013,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // NE entries per thread travel in registers; a longer bucket fetches the rest in place.
     // Every fetch is UNCONDITIONAL at a clamped, always valid address, and nothing looks at a fetched word before the stage that uses
     // it: a load inside a predicated block is followed by its own s_waitcnt vmcnt(0) (32 serialised round trips were seen).
-    // entries per thread that travel in registers.  4K: ~1650 entries per bucket and 512 threads, 1080p: ~240 and 256.  Four help the
-    // forward step at 4K (0.78 -> 0.75 ms per 8-image launch) and cost the inverse step there (0.55 -> 0.60): it keeps two
+    // entries per thread that travel in registers.  4K: ~1650 entries per bucket and 512 threads, 1080p: ~240 and 256.  Four cover a
+    // 4K bucket (a longer one fetches the rest in place, a dependent round trip in the middle of the tile): first inverse step
+    // 0.547 -> 0.512 ms per 8 x 4K launch (round 3, gpurun_out/r3f; round 2's kernel, one workgroup per CU at 247 registers, lost by it)
 #ifndef TFFT_EMBED_NE9
-#define TFFT_EMBED_NE9 2
+#define TFFT_EMBED_NE9 4
 #endif
     constexpr int NE = (LOGL >= 9) ? (MODE == COLS_EMBED ? (LOGL == 9 ? TFFT_EMBED_NE9 : 2) : 4) : 2;
     struct EmEntry { TileBin tb; float2 f; unsigned bit, live; };   // bucket entry, the stored value of its bin (conjugate of the bin when

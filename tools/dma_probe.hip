@@ -7,6 +7,8 @@
 //   V5  V0 with raw barriers (s_waitcnt lgkmcnt(0) + s_barrier) instead of __syncthreads(), whose release fence drains vmcnt
 //   V6  V1 + the 4-byte values of TWO adjacent tiles stored together as 128-byte row segments (8 B per lane after a swap with the
 //       neighbouring lane), instead of two 64-byte segments per row
+//   V7  V2 with the tiles of a row group dealt to PAIRS of workgroups on one XCD (ids 8 apart): one takes the even tiles, the other
+//       the odd ones, so the two 64-byte halves of every 128-byte line are written at about the same time and can merge in the L2
 //   V4  V2 with a COUNTED wait (vmcnt(16): the stores are the youngest 16 operations) -- also the in-order test of vmcnt
 //       across loads, LDS-DMA and stores: its checksums must equal V1's
 // `work` dummy FMA rounds per element stand in for the transform between the barriers.
@@ -39,7 +41,11 @@ __global__ void __launch_bounds__(NT) k_probe(const float2* __restrict__ in, flo
     const int c = threadIdx.x, t = threadIdx.y, tid = t * C + c, w = tid >> 6, lane = tid & 63;
     const int g = blockIdx.y, plane = blockIdx.z;
     const size_t poff = (size_t)plane * PH * M + (size_t)g * L * M;
-    const int tile0 = blockIdx.x * tpb;
+    int tile0 = blockIdx.x * tpb, tstep = 1;
+    if (V == 7) {       // gridDim.x is a multiple of 16: blockIdx.x and blockIdx.x + 8 share an XCD (workgroups go round robin by linear id)
+        const int bx = blockIdx.x, pair = (bx >> 4) * 8 + (bx & 7), par = (bx >> 3) & 1;
+        tile0 = pair * 2 * tpb + par; tstep = 2;
+    }
     float2* buf0 = reinterpret_cast<float2*>(smem);
     float2* buf1 = buf0 + L * C;
     float2 u[16], un[16];
@@ -63,7 +69,7 @@ __global__ void __launch_bounds__(NT) k_probe(const float2* __restrict__ in, flo
         __builtin_amdgcn_s_barrier();
     }
     for (int i = 0; i < tpb; i++) {
-        const int tile = tile0 + i;
+        const int tile = tile0 + i * tstep;
         float2* cur = (i & 1) ? buf1 : buf0;
         float2* nxt = (i & 1) ? buf0 : buf1;
         if (V == 3 && have_d) store_d(dtile);
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(NT) k_probe(const float2* __restrict__ in, flo
             if (V == 0 || V == 5) {
 #pragma unroll
                 for (int m = 0; m < 16; m++) un[m] = in[poff + (size_t)(t + m * T) * M + (tile + 1) * C + c];
-            } else dma_tile(in + poff + (tile + 1) * C, M, (unsigned char*)nxt, w, lane);
+            } else dma_tile(in + poff + (tile + tstep) * C, M, (unsigned char*)nxt, w, lane);
         }
         if (V == 0 || V == 5) {
 #pragma unroll
@@ -89,7 +95,7 @@ __global__ void __launch_bounds__(NT) k_probe(const float2* __restrict__ in, flo
         }
 #pragma unroll
         for (int m = 0; m < 16; m++) { acc += u[m].x + u[m].y; d[m] = u[m].x * u[m].x + u[m].y * u[m].y; }
-        if (V == 2 || V == 4) store_d(tile);
+        if (V == 2 || V == 4 || V == 7) store_d(tile);
         if (V == 3) { have_d = true; dtile = tile; }
         if (V == 6) {
             if (i & 1) {        // odd tile: this lane's value of the even tile (dprev) and of the odd tile (d); even lanes store the even tile's
@@ -159,7 +165,11 @@ int main(int argc, char** argv) {
     const double rb = (double)n * 8, wb = (double)n * 4;
     std::vector<float> ref(nwg), got(nwg);
     for (int work : {0, 8, 16, 24, 32}) {
-        float ms[7];
+        float ms[8];
+        if ((M / C / tpb) % 16 == 0) {
+            ms[7] = run<7>(in, out, sums, M, PH, planes, tpb, work, 5);
+            printf("work %2d | V7 paired workgroups, 64-B stores %.3f ms %.0f GB/s\n", work, ms[7], (rb + wb) / ms[7] / 1e6);
+        }
         ms[5] = run<5>(in, out, sums, M, PH, planes, tpb, work, 5);
         ms[6] = run<6>(in, out, sums, M, PH, planes, tpb, work, 5);
         {   // V6 must write what V2 writes
