@@ -71,11 +71,7 @@ struct tfft_ctx {
                          const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr;
                          const void* row_for = nullptr; uint64_t row_n = 0; int row_ph = 0, row_pw = 0; } tb[2];
     const void* reg_bins = nullptr; uint64_t reg_n = 0;      // tfft_bins_register_dev
-    const ColParams* fwd_emit = nullptr;  // when set, the last forward column step also writes the values of the listed bins (COLS_EMIT, delta embedding)
-    const ColParams* inv_embed = nullptr; // when set, the first inverse column step runs in COLS_EMBED mode (delta embedding) with these rd_*/em_* fields
-    const uint8_t* inv_cover = nullptr;   // ... and the inverse row kernel adds its transform to these cover pixels
     int embed_delta = 1;                  // batched embeds: stego = cover + IFFT(F' - F) (TFFT_EMBED_DELTA=0: write F' into the spectrum and invert it)
-    const ColParams* fwd_read = nullptr;  // when set, the final forward column step runs in COLS_READ mode with these rd_* fields
     int tile_read = 1;                    // TFFT_TILE_READ=0: row-limited spectrum + k_read always; 1: tile read for chunks of >= 8 images; 3: always; 2: always, with the global-atomic bucket build
     hipStream_t stream2 = nullptr;        // TFFT_STREAMS=2: second half of a batch chunk runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -87,7 +83,6 @@ struct tfft_ctx {
     int stats_m2 = 1;                     // batched delta embeds store |F|^2 (half the bytes) for the statistics instead of the spectrum nobody else reads (TFFT_STATS_M2=0)
     int n_streams = 1;
     int n_cus = 0, collect_resident = 0;  // grid sizing of the full median pass: fill every CU to the same depth
-    const int* fwd_last_row = nullptr;    // when set, the final forward column step stores rows <= *fwd_last_row only
     uint32_t* bit_index = nullptr;        // tfft_set_bit_index: bins[i] carries stream bit bit_index[i]
     uint64_t bit_index_n = 0;
     std::map<int, float2*> tw;            // N -> table exp(+2 pi i j/N), j < N
@@ -105,8 +100,9 @@ struct tfft_ctx {
     int cols_direct_max_log = 8;          // PH <= 256: one column pass; taller: two-step N1 x N2 (a direct 512 pass reaches 1.8-3.4 TB/s, the two steps 5-6)
     int cols_force_log_n1 = -1;
     int cols_tiles_per_block = 8;
+    int cols_tiles_forced = 0;            // TFFT_COLS_TILES given: it also rules the COLS_EMIT step (default there: 2 tiles per workgroup up to L = 256, r3h A/B: 0.601 vs 0.630 ms per 32 x 1080p launch)
     int cols_tiles_embed = 0;             // delta embedding: tiles per workgroup of the first inverse step; 0 = 8 for columns up to 256, 2 from 512 on
-                                          // (A/B per 32 x 1080p launch: 0.40 / 0.45 / 0.51 / 0.49 ms with 8 / 4 / 2 / 1; per 8 x 4K: 0.58 / 0.56 / 0.54 with 8 / 2 / 1)
+                                          // (round 3 A/B, gpurun_out/r3h, per 32 x 1080p launch: 0.490 / 0.437 / 0.404 / 0.394 ms with 2 / 4 / 8 / 16; per 8 x 4K: 0.563 / 0.501 / 0.511 / 0.518 with 1 / 2 / 4 / 8)
     int cols_tiles_read = 16;             // the tile-resident read walks longer runs (A/B: 0.422 vs 0.455 ms per 32x1080p launch; the storing steps prefer 8)
     int median_force_fallback = 0;
 #ifndef TFFT_NO_GRAPHS
@@ -211,7 +207,17 @@ static void copy_embed_fields(ColParams& cp, const ColParams& e) {
     cp.st_col0 = e.st_col0;
 }
 
-int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st) {
+// How a launch sequence wants the outer column steps and the inverse row kernel to run: handed down explicitly per call (until round 3
+// these were pointers parked in the context around a call -- to stack objects, and left dangling by any early return in between).
+struct StageMode {
+    const ColParams* fwd_emit = nullptr;   // the last forward column step also writes the values of the listed bins (COLS_EMIT, delta embedding)
+    const ColParams* fwd_read = nullptr;   // the last forward column step runs in COLS_READ mode with these rd_* fields (no spectrum stored)
+    const int* fwd_last_row = nullptr;     // the last forward column step stores rows <= *fwd_last_row only (COLS_ROWLIMIT)
+    const ColParams* inv_embed = nullptr;  // the first inverse column step runs in COLS_EMBED mode (delta embedding) with these rd_*/em_* fields
+    const uint8_t* inv_cover = nullptr;    // ... and the inverse row kernel adds its transform to these cover pixels
+};
+
+int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st, const StageMode& md = StageMode()) {
     const Slot& s = c->slots[s0];
     const int M = s.PWi / 2;
     const float2 *tw_w, *tw_h;
@@ -236,13 +242,13 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             if (pl.fused_fwd) return TFFT_OK;       // done inside ROWS_FWD
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 0;
-                cp.last_row_dev = c->fwd_last_row;
+                cp.last_row_dev = md.fwd_last_row;
             if (c->dc_bias != 0.0f) {
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-                if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
-                else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
+                if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
+                else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
                 HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
@@ -253,19 +259,19 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             if (pl.direct) return TFFT_OK;
             // for every k1: length-N2 FFT over rows k1*N2+n2 -> rows k1+N1*k2
             cp.G = N1; cp.in_a = 1; cp.in_b = N2; cp.out_a = N1; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 0;
-            cp.last_row_dev = c->fwd_last_row;
+            cp.last_row_dev = md.fwd_last_row;
             if (c->dc_bias != 0.0f) {
                 rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
-            if (c->fwd_read) { const ColParams& r = *c->fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
-            else if (c->fwd_emit) copy_embed_fields(cp, *c->fwd_emit);
+            if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
+            else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
             HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
                 cp.G = 1; cp.in_a = 1; cp.in_b = 0; cp.out_a = 1; cp.out_b = 0; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-                if (c->inv_embed) { copy_embed_fields(cp, *c->inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 8); }
+                if (md.inv_embed) { copy_embed_fields(cp, *md.inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 16); }
                 else if (c->dc_bias != 0.0f) {
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
@@ -273,7 +279,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
                 cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
-                if (c->inv_embed) { copy_embed_fields(cp, *c->inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 8); }
+                if (md.inv_embed) { copy_embed_fields(cp, *md.inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 16); }
                 else if (c->dc_bias != 0.0f) {
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
@@ -289,7 +295,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             return TFFT_OK;
         case ROWS_INV: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias, nullptr};
-            if (c->inv_cover) { rp.cover = c->inv_cover; rp.bias = 0.f; }      // delta embedding: the transform of F' - F has no DC term to give back
+            if (md.inv_cover) { rp.cover = md.inv_cover; rp.bias = 0.f; }      // delta embedding: the transform of F' - F has no DC term to give back
             if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
             else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
@@ -299,9 +305,9 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
 }
 
 // forward: rows (u8 -> tmp) then columns (tmp -> spec) for slots [s0, s0+n); images contiguous at rgb_dev
-int enqueue_forward(tfft_ctx* c, int s0, int n, const uint8_t* rgb_dev, hipStream_t st) {
+int enqueue_forward(tfft_ctx* c, int s0, int n, const uint8_t* rgb_dev, hipStream_t st, const StageMode& md = StageMode()) {
     for (int stage : {ROWS_FWD, COLS_FWD_A, COLS_FWD_B}) {
-        int rc = enqueue_fft_stage(c, s0, n, stage, rgb_dev, nullptr, st);
+        int rc = enqueue_fft_stage(c, s0, n, stage, rgb_dev, nullptr, st, md);
         if (rc) return rc;
     }
     for (int i = 0; i < n; i++) { c->slots[s0 + i].has_spec = true; c->slots[s0 + i].rgb_src = nullptr; }
@@ -309,9 +315,9 @@ int enqueue_forward(tfft_ctx* c, int s0, int n, const uint8_t* rgb_dev, hipStrea
 }
 
 // inverse: columns (spec -> tmp, only rows < H kept) then rows (tmp -> u8)
-int enqueue_inverse(tfft_ctx* c, int s0, int n, uint8_t* rgb_out_dev, hipStream_t st) {
+int enqueue_inverse(tfft_ctx* c, int s0, int n, uint8_t* rgb_out_dev, hipStream_t st, const StageMode& md = StageMode()) {
     for (int stage : {COLS_INV_A, COLS_INV_B, ROWS_INV}) {
-        int rc = enqueue_fft_stage(c, s0, n, stage, nullptr, rgb_out_dev, st);
+        int rc = enqueue_fft_stage(c, s0, n, stage, nullptr, rgb_out_dev, st, md);
         if (rc) return rc;
     }
     for (int i = 0; i < n; i++) c->slots[s0 + i].has_spec = false;
@@ -538,7 +544,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_FUSED")) c->stats_fused = atoi(e);
     if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
-    if (const char* e = getenv("TFFT_COLS_TILES")) c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
@@ -927,10 +933,10 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way).  (On the side stream
         // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
-        c->fwd_emit = &em;
     }
-    rc = enqueue_forward(c, s0, g, rgb_in, st);
-    c->fwd_emit = nullptr;
+    StageMode md;
+    if (delta) md.fwd_emit = &em;
+    rc = enqueue_forward(c, s0, g, rgb_in, st, md);
     if (rc) return rc;
     hipStream_t sst = st;       // the stream the statistics run on
     const bool async = delta && usable && c->stats_async;
@@ -957,9 +963,9 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         }
     }
     if (delta) {
-        c->inv_embed = &em; c->inv_cover = rgb_in;
-        rc = enqueue_inverse(c, s0, g, rgb_out, st);
-        c->inv_embed = nullptr; c->inv_cover = nullptr;
+        StageMode mi;
+        mi.inv_embed = &em; mi.inv_cover = rgb_in;
+        rc = enqueue_inverse(c, s0, g, rgb_out, st, mi);
         if (async) {            // whoever waits for the context's stream has the capacities too
             HIPCHK(c, hipEventRecord(c->ev_stats_join[which], sst));
             HIPCHK(c, hipStreamWaitEvent(st, c->ev_stats_join[which], 0));
@@ -994,9 +1000,9 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
         if (rc) return rc;
         ColParams rd{};
         rd.rd_bins = tb.ent; rd.rd_off = tb.off; rd.rd_bits = bits_out; rd.rd_n = n_bits; rd.trash = c->trash;
-        c->fwd_read = &rd;
-        rc = enqueue_forward(c, s0, g, rgb_in, st);
-        c->fwd_read = nullptr;
+        StageMode md;
+        md.fwd_read = &rd;
+        rc = enqueue_forward(c, s0, g, rgb_in, st, md);
         if (rc) return rc;
     } else {
         // the spectrum is only read at the bins of the list: rows above the highest one are never stored
@@ -1007,9 +1013,9 @@ static int extract_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, cons
             HIPCHK(c, launch_bins_last_row(bins, n_bits, s.PH, s.PWi, last_row, st));
             tbr.row_for = registered ? bins : nullptr; tbr.row_n = n_bits; tbr.row_ph = s.PH; tbr.row_pw = s.PWi;
         }
-        c->fwd_last_row = last_row;
-        rc = enqueue_forward(c, s0, g, rgb_in, st);
-        c->fwd_last_row = nullptr;
+        StageMode md;
+        md.fwd_last_row = last_row;
+        rc = enqueue_forward(c, s0, g, rgb_in, st, md);
         if (rc) return rc;
         HIPCHK(c, launch_read(c->spec(s0), bins, nullptr, ep, g, bits_out, c->err, st));
     }
@@ -1435,24 +1441,20 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         switch (stage) {
             case COLS_FWD_A:
             case COLS_FWD_B:
-                if (em.rd_bins && stage == final_fwd) c->fwd_emit = &em;
-                rc = enqueue_fft_stage(c, 0, n_images, stage, (const uint8_t*)rgb_dev, nullptr, c->stream);
-                c->fwd_emit = nullptr;
+                { StageMode md; if (em.rd_bins && stage == final_fwd) md.fwd_emit = &em;
+                  rc = enqueue_fft_stage(c, 0, n_images, stage, (const uint8_t*)rgb_dev, nullptr, c->stream, md); }
                 break;
             case COLS_INV_A:
-                if (em.rd_bins) c->inv_embed = &em;
-                rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, nullptr, c->stream);
-                c->inv_embed = nullptr;
+                { StageMode md; if (em.rd_bins) md.inv_embed = &em;
+                  rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, nullptr, c->stream, md); }
                 break;
             case ROWS_INV:
-                if (delta && rgb_dev) c->inv_cover = (const uint8_t*)rgb_dev;
-                rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, (uint8_t*)rgb_out_dev, c->stream);
-                c->inv_cover = nullptr;
+                { StageMode md; if (delta && rgb_dev) md.inv_cover = (const uint8_t*)rgb_dev;
+                  rc = enqueue_fft_stage(c, 0, n_images, stage, nullptr, (uint8_t*)rgb_out_dev, c->stream, md); }
                 break;
             case COLS_FWD_READ:
-                if (rd.rd_bins) c->fwd_read = &rd; else c->fwd_last_row = c->last_row;
-                rc = enqueue_fft_stage(c, 0, n_images, final_fwd, nullptr, nullptr, c->stream);
-                c->fwd_read = nullptr; c->fwd_last_row = nullptr;
+                { StageMode md; if (rd.rd_bins) md.fwd_read = &rd; else md.fwd_last_row = c->last_row;
+                  rc = enqueue_fft_stage(c, 0, n_images, final_fwd, nullptr, nullptr, c->stream, md); }
                 break;
             case EMBED: {
                 if (!index_ok(c, n_bits)) return TFFT_E_STATE;
