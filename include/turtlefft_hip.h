@@ -90,15 +90,25 @@ int tfft_forward_rgb8(tfft_ctx* ctx, int slot, const uint8_t* rgb, int w, int h,
 int tfft_forward_rgb8_dev(tfft_ctx* ctx, int slot, const void* rgb_dev, int w, int h, int center, int* pw, int* ph);
 
 /* median_abs x3 (S:922, S:404-409): element at sorted index P/2 of |F| over
- * the FULL padded plane (mirror bins counted).  Synchronises. */
+ * the FULL padded plane (mirror bins counted).  Synchronises.
+ * EXACT against the reference's fp64 spectrum (to ~1e-13 relative: two fp64 summation orders): the fp32 spectrum locates the
+ * element, the handful of bins within 2e-6 of it are re-evaluated in fp64 from the pixels (tfft_exact.hip), and rank and value
+ * are settled on those.  Needs the image of the last tfft_forward_rgb8[_dev] of the slot to be still in place (the _dev form
+ * keeps the caller's pointer, like tfft_lowfreq_mag) and PW <= 8192; otherwise -- and with TFFT_EXACT_STATS=0 -- the order
+ * statistic of the fp32 magnitudes is returned (2e-6 relative).  tfft_exact_info tells which. */
 int tfft_medians(tfft_ctx* ctx, int slot, double med[3]);
+/* bins per plane the last tfft_medians / tfft_capacity of this context re-evaluated in fp64 (0: the fp32 answer was returned) */
+int tfft_exact_info(const tfft_ctx* ctx, int n_fp64[3]);
 
 /* Diagnostic: how the last tfft_medians / batched median of `slot` was obtained, per plane:
  * 1 = sampled bracket + one verified pass (fast path), 0 = full three-level select (fallback). */
 int tfft_median_path(tfft_ctx* ctx, int slot, int fast[3]);
 
 /* count_plane (S:998-1008): sum over planes of floor(c/2), c = bins in the
- * annulus [rmin,rmax]*min(PH,PW), off the axes, |F| >= thr[plane].  Synchronises. */
+ * annulus [rmin,rmax]*min(PH,PW), off the axes, |F| >= thr[plane].  Synchronises.
+ * EXACT like tfft_medians (same conditions): bins within 1e-3 of thr are settled on their fp64 magnitudes, so with
+ * thr = magmin * tfft_medians() the count is the reference's integer.  The batched pipelines' usable_out stays the count on the
+ * fp32 planes (observed 0-1 off, bound 2: a bin within fp32 rounding of the threshold), see DESIGN.md section 2. */
 int tfft_capacity(tfft_ctx* ctx, int slot, double rmin, double rmax, const double thr[3], uint64_t* usable);
 
 /* compute_cover_hash's magnitudes (S:428-436): |F[y][x]| for y,x < region (<= 8) of

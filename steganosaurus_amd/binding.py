@@ -41,6 +41,7 @@ SYMBOLS = {
     "tfft_capacity": (_i, [_vp, _i, _d, _d, _vp, C.POINTER(_u64)]),
     "tfft_lowfreq_mag": (_i, [_vp, _i, _i, _vp]),
     "tfft_embed_bins": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _d, _i, _vp]),
+    "tfft_exact_info": (_i, [_vp, _vp]),
     "tfft_embed_bins_dev": (_i, [_vp, _i, _vp, _vp, _vp, _u64, _d, _i, _vp]),
     "tfft_read_bins": (_i, [_vp, _i, _vp, _vp, _u64, _d, _i, _vp, _vp]),
     "tfft_read_bins_dev": (_i, [_vp, _i, _vp, _vp, _u64, _d, _i, _vp, _vp]),
@@ -244,6 +245,12 @@ class Context:
         med = np.zeros(3, np.float64)
         _check(self.lib.tfft_medians(self.h, slot, _ptr(med)), "tfft_medians")
         return med
+
+    def exact_info(self):
+        """bins per plane the last medians() / capacity() re-evaluated in fp64 (0: the fp32 answer was returned)"""
+        out = np.zeros(3, np.int32)
+        _check(self.lib.tfft_exact_info(self.h, _ptr(out)), "tfft_exact_info")
+        return [int(v) for v in out]
 
     def median_path(self, slot=0):
         """Per plane: 1 if the last median came from the sampled fast path, 0 if from the full fallback."""

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <complex>
 #include <map>
 #include <tuple>
@@ -61,6 +62,11 @@ struct tfft_ctx {
     unsigned* partial = nullptr;          // [n_slots*3*TFFT_STAT_MAX_BLOCKS + n_slots]
     float* amb = nullptr;                 // [n_slots*3*TFFT_AMB_CAP] |F|^2 of the bins the bracket pass could not decide
     unsigned long long* usable = nullptr; // [n_slots]
+    // exact medians / capacity of the single-image calls (tfft_exact.hip): candidate lists, counters, fp64 values
+    int exact_stats = 1;                  // TFFT_EXACT_STATS=0: tfft_medians / tfft_capacity return the fp32 spectrum's own statistics
+    ExactCand* ex_cand = nullptr; double2* ex_val = nullptr; unsigned long long* ex_below = nullptr; unsigned* ex_n = nullptr;
+    std::map<int, double2*> ex_table;     // PW -> exp(2 pi i j/PW) in fp64
+    int ex_last[3] = {0, 0, 0};           // diagnostics: candidates evaluated per plane by the last exact call (0: fp32 result returned)
     int* err = nullptr;                   // sticky bin-range flag
     uint8_t* trash = nullptr;             // 8 KiB nobody reads: target of the unpredicated list stores of lanes without an entry (ColParams::trash)
     int* last_row = nullptr;              // device scalars of k_bins_last_row, one per compute stream
@@ -544,6 +550,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_FUSED")) c->stats_fused = atoi(e);
     if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
+    if (const char* e = getenv("TFFT_EXACT_STATS")) c->exact_stats = atoi(e);
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
@@ -585,7 +592,7 @@ int tfft_destroy(tfft_ctx* c) {
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
     (void)hipFree(c->col0_pool);
-    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->trash); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
+    (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->ex_cand); (void)hipFree(c->ex_val); (void)hipFree(c->ex_below); (void)hipFree(c->ex_n); for (auto& kv : c->ex_table) (void)hipFree(kv.second); (void)hipFree(c->trash); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->dc) (void)hipFree(kv.second);
@@ -663,6 +670,111 @@ int tfft_forward_rgb8(tfft_ctx* c, int slot, const uint8_t* rgb, int w, int h, i
     return rc;
 }
 
+// ---- exact statistics of a single resident image (tfft_exact.hip): the bins whose fp32 magnitude lies within a window of the decision
+// value are re-evaluated in fp64 from the pixels, everything else is counted on the fp32 spectrum
+namespace {
+constexpr int EX_CAP = 4096;          // candidate slots per plane
+constexpr int EX_SPLIT = 64;          // workgroups (row ranges) a candidate's sum is dealt to, at most
+
+int exact_buffers(tfft_ctx* c) {
+    if (c->ex_cand) return TFFT_OK;
+    if (dev_alloc(c, (void**)&c->ex_cand, (size_t)3 * EX_CAP * sizeof(ExactCand)) || dev_alloc(c, (void**)&c->ex_val, (size_t)3 * EX_CAP * EX_SPLIT * sizeof(double2)) ||
+        dev_alloc(c, (void**)&c->ex_below, 3 * sizeof(unsigned long long)) || dev_alloc(c, (void**)&c->ex_n, 3 * sizeof(unsigned)))
+        return TFFT_E_NOMEM;
+    return TFFT_OK;
+}
+bool exact_possible(const tfft_ctx* c, const Slot& s) {
+    return c->exact_stats && s.rgb_src && s.PW == s.PWi && s.PWi <= 8192 && s.PH <= 65535 && s.PWi <= 65535;
+}
+struct ExactOut { std::vector<ExactCand> cand[3]; std::vector<double> mag[3]; unsigned long long outside[3]; };
+// one collect + evaluate round with the fp32 |F|^2 windows [lo2, hi2] per plane; false in `ok` when a candidate list overflowed
+int exact_round(tfft_ctx* c, int slot, const ExactCollect& P, ExactOut& o, bool& ok) {
+    const Slot& s = c->slots[slot];
+    int rc = exact_buffers(c);
+    if (rc) return rc;
+    HIPCHK(c, launch_exact_collect(c->spec(slot), P, c->ex_cand, c->ex_below, c->ex_n, c->stream));
+    unsigned n[3];
+    HIPCHK(c, hipMemcpyAsync(n, c->ex_n, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(o.outside, c->ex_below, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ok = n[0] <= (unsigned)EX_CAP && n[1] <= (unsigned)EX_CAP && n[2] <= (unsigned)EX_CAP;
+    if (!ok) return TFFT_OK;
+    double2* table = nullptr;
+    {
+        auto it = c->ex_table.find(s.PWi);
+        if (it == c->ex_table.end()) {
+            if (dev_alloc(c, (void**)&table, (size_t)s.PWi * sizeof(double2))) return TFFT_E_NOMEM;
+            HIPCHK(c, launch_exact_table(table, s.PWi, c->stream));
+            c->ex_table[s.PWi] = table;
+        } else table = it->second;
+    }
+    int split = s.H / 32;
+    if (split < 1) split = 1;
+    if (split > EX_SPLIT) split = EX_SPLIT;
+    for (int p = 0; p < 3; p++) {
+        o.cand[p].resize(n[p]); o.mag[p].resize(n[p]);
+        if (!n[p]) continue;
+        HIPCHK(c, launch_exact_eval(s.rgb_src, s.W, s.H, s.PWi, s.PH, s.center, c->ex_cand + (size_t)p * EX_CAP, n[p], split, table,
+                                    c->ex_val + (size_t)p * EX_CAP * EX_SPLIT, c->stream));
+    }
+    std::vector<double2> v((size_t)EX_CAP * EX_SPLIT);
+    for (int p = 0; p < 3; p++) {
+        if (!n[p]) continue;
+        HIPCHK(c, hipMemcpyAsync(o.cand[p].data(), c->ex_cand + (size_t)p * EX_CAP, n[p] * sizeof(ExactCand), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(v.data(), c->ex_val + (size_t)p * EX_CAP * EX_SPLIT, (size_t)n[p] * split * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (unsigned i = 0; i < n[p]; i++) {
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < split; k++) { re += v[(size_t)i * split + k].x; im += v[(size_t)i * split + k].y; }      // fixed order: deterministic
+            o.mag[p][i] = hypot(re, im);      // std::abs(complex<double>) of S:406 / S:1004
+        }
+    }
+    return TFFT_OK;
+}
+// fp32 window around a decision value d (> 0) on |F|^2: relative half-width `rel`, rounded outwards
+void exact_window(double d, double rel, float& lo2, float& hi2) {
+    const double lo = d * (1.0 - rel), hi = d * (1.0 + rel);
+    lo2 = nextafterf((float)(lo * lo), -INFINITY); hi2 = nextafterf((float)(hi * hi), INFINITY);
+    if (!(lo2 > 0.f)) lo2 = 0.f;
+}
+// median_abs S:404-409 for the three planes, refined from the fp32 medians m32; false when the refinement did not apply
+bool exact_medians(tfft_ctx* c, int slot, const float m32[3], double med[3], int* rc_out) {
+    const Slot& s = c->slots[slot];
+    *rc_out = TFFT_OK;
+    c->ex_last[0] = c->ex_last[1] = c->ex_last[2] = 0;
+    if (!exact_possible(c, s)) return false;
+    const unsigned long long rank = ((unsigned long long)s.PH * s.PW) / 2;
+    double rel = 2e-6;                   // ~16 sigma of the fp32 transform's error at the median's magnitude (measured 1.2e-7 relative)
+    for (int attempt = 0; attempt < 5; attempt++, rel *= 4.0) {
+        ExactCollect P{};
+        P.PH = s.PH; P.PW = s.PWi; P.PW_full = s.PW; P.cap = 0; P.cap_cand = EX_CAP;
+        for (int p = 0; p < 3; p++) exact_window((double)m32[p], rel, P.lo2[p], P.hi2[p]);
+        ExactOut o; bool ok = false;
+        int rc = exact_round(c, slot, P, o, ok);
+        if (rc) { *rc_out = rc; return false; }
+        if (!ok) return false;           // a flat spectrum (thousands of bins within 1e-6 of the median): keep the fp32 answer
+        bool good = true;
+        for (int p = 0; p < 3 && good; p++) {
+            const size_t n = o.cand[p].size();
+            unsigned long long wsum = 0; double emax = 0.0;
+            for (size_t i = 0; i < n; i++) { wsum += o.cand[p][i].w; emax = fmax(emax, fabs(o.mag[p][i] - sqrt((double)o.cand[p][i].m2))); }
+            // the window must hold the rank, and be wide against the fp32 error actually seen on its own bins (else a bin outside it
+            // could belong inside): 4 x the largest error
+            if (!(o.outside[p] <= rank && rank < o.outside[p] + wsum) || 4.0 * emax > rel * (double)m32[p]) { good = false; break; }
+            std::vector<size_t> ord(n);
+            for (size_t i = 0; i < n; i++) ord[i] = i;
+            std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return o.mag[p][a] < o.mag[p][b]; });
+            unsigned long long cum = o.outside[p];
+            med[p] = (double)m32[p];
+            for (size_t k = 0; k < n; k++) { cum += o.cand[p][ord[k]].w; if (rank < cum) { med[p] = o.mag[p][ord[k]]; break; } }
+            c->ex_last[p] = (int)n;
+        }
+        if (good) return true;
+    }
+    return false;
+}
+}  // namespace
+
 int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
     if (!slot_ok(c, slot) || !med) return TFFT_E_INVALID;
     if (!c->slots[slot].has_spec) return TFFT_E_STATE;
@@ -672,6 +784,15 @@ int tfft_medians(tfft_ctx* c, int slot, double med[3]) {
     HIPCHK(c, hipMemcpyAsync(m, c->med + 3 * slot, sizeof m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) med[i] = (double)m[i];
+    // the fp32 medians locate the element; its value (and which of the near-equal neighbours it is) comes from fp64 sums over the pixels
+    double ex[3];
+    if (exact_medians(c, slot, m, ex, &rc)) { for (int i = 0; i < 3; i++) med[i] = ex[i]; }
+    return rc;
+}
+
+int tfft_exact_info(const tfft_ctx* c, int n_fp64[3]) {
+    if (!c || !n_fp64) return TFFT_E_INVALID;
+    for (int i = 0; i < 3; i++) n_fp64[i] = c->ex_last[i];
     return TFFT_OK;
 }
 
@@ -693,6 +814,37 @@ int tfft_capacity(tfft_ctx* c, int slot, double rmin, double rmax, const double 
     if (!s.has_spec) return TFFT_E_STATE;
     CapParams p = cap_params(c, s, rmin, rmax);
     for (int i = 0; i < 3; i++) p.thr[i] = thr[i];
+    // exact count (S:998-1008 on the reference's fp64 magnitudes): bins safely above the threshold are counted on the fp32 spectrum, the
+    // few within a window of it are settled in fp64.  Small magnitudes carry the transform's ABSOLUTE error (~1e-7 of the spectrum's rms),
+    // hence the wide relative window (1e-3) and the check against the error seen on the window's own bins.
+    c->ex_last[0] = c->ex_last[1] = c->ex_last[2] = 0;
+    if (exact_possible(c, s) && p.bw > 0 && thr[0] > 0.0 && thr[1] > 0.0 && thr[2] > 0.0) {
+        double rel = 1e-3;
+        for (int attempt = 0; attempt < 4; attempt++, rel *= 4.0) {
+            ExactCollect P{};
+            P.PH = s.PH; P.PW = s.PWi; P.PW_full = s.PW; P.cap = 1; P.cap_cand = EX_CAP; P.s_lo = p.s_lo; P.s_hi = p.s_hi;
+            for (int q = 0; q < 3; q++) exact_window(thr[q], rel, P.lo2[q], P.hi2[q]);
+            ExactOut o; bool ok = false;
+            int rc = exact_round(c, slot, P, o, ok);
+            if (rc) return rc;
+            if (!ok) break;
+            bool good = true;
+            unsigned long long total = 0;
+            for (int q = 0; q < 3 && good; q++) {
+                unsigned long long cnt = o.outside[q];
+                double emax = 0.0;
+                for (size_t i = 0; i < o.cand[q].size(); i++) {
+                    emax = fmax(emax, fabs(o.mag[q][i] - sqrt((double)o.cand[q][i].m2)));
+                    if (!(o.mag[q][i] < thr[q])) cnt += o.cand[q][i].w;          // S:1004: `if (std::abs(F) < thr) continue`
+                }
+                if (4.0 * emax > rel * thr[q]) good = false;
+                total += cnt / 2;                                                  // S:1007: c/2 per plane
+                c->ex_last[q] = (int)o.cand[q].size();
+            }
+            if (good) { *usable = total; return TFFT_OK; }
+        }
+        c->ex_last[0] = c->ex_last[1] = c->ex_last[2] = 0;
+    }
     HIPCHK(c, launch_capacity(c->spec(slot), p, 1, nullptr, c->partial + (size_t)3 * slot * TFFT_STAT_MAX_BLOCKS,
                               c->usable + slot, c->stream));
     unsigned long long u = 0;

@@ -103,6 +103,22 @@ __host__ __device__ inline float mag2_threshold(double thr) {
     return c;
 }
 
+// ---- exact medians / capacity of the single-image calls (tfft_exact.hip)
+struct ExactCand { uint16_t y, x, w, plane; float m2; };      // a full-grid bin (x = PW/2: the Nyquist column out of the packed column 0), the
+                                                              // weight it carries (itself and / or its Hermitian mirror) and its fp32 |F|^2
+struct ExactCollect {
+    int PH, PW;                       // padded grid (PW = the internal even row length)
+    int PW_full;                      // the reference's PW (mirror columns are PW_full - x)
+    int cap;                          // 0: median mode, 1: capacity mode (annulus s_lo <= y*y + x*x <= s_hi, axes excluded)
+    unsigned long long s_lo, s_hi;
+    float lo2[3], hi2[3];             // per plane: window of fp32 |F|^2 whose bins are re-evaluated in fp64
+    int cap_cand;                     // candidate slots per plane
+};
+hipError_t launch_exact_collect(const float2* spec, const ExactCollect& P, ExactCand* cand, unsigned long long* below, unsigned* n_cand, hipStream_t s);
+hipError_t launch_exact_table(double2* table, int PW, hipStream_t s);
+hipError_t launch_exact_eval(const uint8_t* rgb, int W, int H, int PW, int PH, int center, const ExactCand* cand, unsigned n, int n_split,
+                             const double2* table, double2* out, hipStream_t s);
+
 #define TFFT_STAT_MAX_BLOCKS 512
 
 struct SelectState {        // one per (image, plane)

@@ -69,6 +69,7 @@ static inline unsigned emu_alignbyte(unsigned hi, unsigned lo, unsigned sh) { re
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu_launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
 
+static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); if (x == floor(x)) *s = 0.0; if (x - floor(x) == 0.5) *c = 0.0; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p += v; return o; }

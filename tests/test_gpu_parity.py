@@ -73,9 +73,9 @@ def test_forward_512_golden_sample(lib, golden_dir, name):
         assert abs(np.linalg.norm(F[p].astype(np.complex128)) - l2) / l2 < 1e-6
         assert np.abs(F[p][:, 0] - g["col0"][p]).max() < 1e-5 * np.abs(g["col0"][p]).max()
         assert np.abs(F[p][:, 256] - g["colN"][p]).max() < 1e-4 * rms
-    assert np.allclose(ctx.medians(), g["med"], rtol=2e-6)
+    assert np.allclose(ctx.medians(), g["med"], rtol=1e-12, atol=0)          # exact: tfft_exact.hip
     cap = ctx.capacity(0.01 * ctx.medians())
-    assert abs(cap - int(g["capacity"])) <= 2
+    assert cap == int(g["capacity"])
     ctx.close()
 
 
@@ -485,6 +485,46 @@ def test_full_size_embed_extract_against_oracle(lib, orc, w, h, secret):
     r = PC.check_embed_extract(lib, orc, w, h, n, dict())
     # non-power-of-two covers do not round-trip in the reference either (SURVEY finding 1): same raw BER class
     assert abs(r["ber_gpu"] - r["ber_ref"]) < 0.01, r
+
+
+@pytest.mark.parametrize("w,h,center", [(1920, 1080, 0), (3840, 2160, 1), (2048, 2048, 0)])
+def test_exact_statistics_at_full_size(lib, orc, w, h, center):
+    """median_abs (S:404-409) and count_plane (S:998-1008) at the BASELINE sizes against the reference's fp64 values: the medians to
+    1e-12 relative and the capacity as the same INTEGER (tfft_exact.hip re-evaluates the bins within the fp32 error of the median /
+    the threshold in fp64 from the pixels).  Also with the forced fallback median, and how long the exact calls take."""
+    import time
+    img = cover_rgb(w, h, 5)
+    cap_want, med_want = orc.capacity_rgb8(img, Params(center=center))
+    for fallback in ("0", "1"):
+        os.environ["TFFT_MEDIAN_FALLBACK"] = fallback
+        try:
+            ctx = B.Context(w, h, lib=lib)
+        finally:
+            os.environ.pop("TFFT_MEDIAN_FALLBACK", None)
+        ctx.forward_rgb8(img, center)
+        t0 = time.perf_counter()
+        med = ctx.medians()
+        t1 = time.perf_counter()
+        n_med = ctx.exact_info()
+        assert all(n > 0 for n in n_med), n_med
+        assert np.allclose(med, med_want, rtol=1e-12, atol=0), (med, med_want)
+        cap = ctx.capacity(0.01 * med)
+        t2 = time.perf_counter()
+        assert cap == cap_want, (cap, cap_want, ctx.exact_info())
+        print("exact statistics %dx%d: medians %.2f ms (%s bins in fp64), capacity %.2f ms (%s bins)" % (w, h, (t1 - t0) * 1e3, n_med, (t2 - t1) * 1e3, ctx.exact_info()))
+        ctx.close()
+    # TFFT_EXACT_STATS=0: the fp32 spectrum's own statistics, inside their old bars
+    os.environ["TFFT_EXACT_STATS"] = "0"
+    try:
+        ctx = B.Context(w, h, lib=lib)
+    finally:
+        os.environ.pop("TFFT_EXACT_STATS", None)
+    ctx.forward_rgb8(img, center)
+    med = ctx.medians()
+    assert ctx.exact_info() == [0, 0, 0]
+    assert np.allclose(med, med_want, rtol=2e-6)
+    assert abs(ctx.capacity(0.01 * med) - cap_want) <= 2
+    ctx.close()
 
 
 def test_batch_1080p_against_oracle(lib, orc):
