@@ -523,6 +523,8 @@ def main():
         out["stages"] = res["stages"]
         if world == 1 and not args.batched_only:
             out["pcie_inclusive"] = pcie_leg(wl, torch)
+        if world == 1 and not args.batched_only:
+            out["png_inclusive"] = png_leg(wl, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, S)
     wl.close()
@@ -594,6 +596,62 @@ def pcie_leg(wl, torch):
             "stego_identical_to_resident_run": same,
             "note": "pinned host buffers through tfft_embed_stream_batch / tfft_extract_stream_batch: H2D of covers and packed stream bytes, "
                     "kernels and D2H of stego / header / payload / status overlapped on three HIP streams"}
+
+
+def png_leg(wl, torch):
+    """side figure, never `value`: PNG FILES in, PNG files out -- libtfpipe.so inflates the covers on worker threads into
+    pinned buffers, feeds tfft_embed_stream_batch / tfft_extract_stream_batch chunk by chunk and deflates the stego images, the three stages
+    overlapped; the codec (zlib on the host cores this process may use) is what the rate measures once the kernels are this fast"""
+    import ctypes as C
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from steganosaurus_amd import binding as B
+    if os.environ.get("TFFT_LIB"):
+        return {"skipped": "an A/B build of the device library is loaded (libtfpipe.so links the shipped one)"}
+    n = min(16, wl.n_img)
+    W, H = wl.W, wl.H
+    cores, how = usable_cores()
+    threads = max(1, min(32, cores))
+    host = C.CDLL(os.path.join(ROOT, "steganosaurus_amd", "libtfhost.so"))
+    d = tempfile.mkdtemp(prefix="tfft_png_")
+    try:
+        ins = [os.path.join(d, "c%02d.png" % i) for i in range(n)]
+        outs = [os.path.join(d, "s%02d.png" % i) for i in range(n)]
+
+        def wr(i):
+            return host.tfh_png_write(ins[i].encode(), wl.covers[i].ctypes.data_as(C.c_void_p), W, H)
+        with ThreadPoolExecutor(threads) as ex:
+            assert all(r == 0 for r in ex.map(wr, range(n)))
+        in_bytes = sum(os.path.getsize(p) for p in ins)
+        ctx = wl.S.Context(W, H, slots=min(8, n), device=wl.dev.index or 0)
+        bins = np.ascontiguousarray(wl.bins_walk)
+        chunk = min(8, n)
+        B.embed_png_batch(ctx, ins[:chunk], outs[:chunk], W, H, bins, wl.header[:chunk], wl.payload[:chunk], chunk=chunk, threads=threads, png_level=1)   # warm-up
+        t0 = time.perf_counter()
+        usable, ms_e = B.embed_png_batch(ctx, ins, outs, W, H, bins, wl.header[:n], wl.payload[:n], chunk=chunk, threads=threads, png_level=1)
+        t1 = time.perf_counter()
+        hdr, pay, st, ms_x = B.extract_png_batch(ctx, outs, W, H, bins, wl.plen, chunk=chunk, threads=threads)
+        t2 = time.perf_counter()
+        out_bytes = sum(os.path.getsize(p) for p in outs)
+        # the files must hold what the resident run produced for the same images: read one back
+        back = np.zeros((H, W, 3), np.uint8)
+        w_, h_ = C.c_int(0), C.c_int(0)
+        assert host.tfh_image_read(outs[0].encode(), back.ctypes.data_as(C.c_void_p), C.c_uint64(back.size), C.byref(w_), C.byref(h_)) == 0
+        wl.embed()
+        wl.ctx.sync()
+        same = bool((back == wl.d_stego[0].cpu().numpy()).all())
+        ctx.close()
+        return {"value": round(n * W * H / (t2 - t0) / 1e6, 1), "unit": "MPixels/s", "images": n, "threads": threads, "cores": how,
+                "embed_ms": round((t1 - t0) * 1e3, 1), "extract_ms": round((t2 - t1) * 1e3, 1),
+                "embed_stage_ms": {"wall": round(ms_e[0], 1), "decode_thread_sum": round(ms_e[1], 1), "device_calls": round(ms_e[2], 1), "encode_thread_sum": round(ms_e[3], 1)},
+                "extract_stage_ms": {"wall": round(ms_x[0], 1), "decode_thread_sum": round(ms_x[1], 1), "device_calls": round(ms_x[2], 1)},
+                "png_bytes_in": in_bytes, "png_bytes_out": out_bytes, "png_level_out": 1,
+                "stego_file_identical_to_resident_run": same,
+                "note": "PNG inflate (zlib) -> pinned buffers -> tfft_embed_stream_batch -> PNG deflate (level 1, 'up' filter) + file write, then the same files "
+                        "through inflate -> tfft_extract_stream_batch; decode / device / encode overlapped chunk by chunk (include/turtlefft_pipe.h)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(wl, S):

@@ -396,3 +396,59 @@ class Context:
         ms = C.c_float(0)
         _check(self.lib.tfft_timer_end(self.h, C.byref(ms)), "tfft_timer_end")
         return ms.value
+
+
+# ---- PNG files -> GPU -> PNG files (libtfpipe.so, include/turtlefft_pipe.h) ---------------------------------------------
+_PIPE = None
+
+
+def load_pipe():
+    """libtfpipe.so next to the device library (raises when it is missing, like load())"""
+    global _PIPE
+    if _PIPE is None:
+        path = os.path.join(_PKG, "libtfpipe.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libtfpipe.so is not built (make -C steganosaurus_amd/csrc)")
+        lib = C.CDLL(path)
+        lib.tfp_embed_png_batch.restype = C.c_int
+        lib.tfp_embed_png_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
+                                            C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]
+        lib.tfp_extract_png_batch.restype = C.c_int
+        lib.tfp_extract_png_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_double,
+                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _PIPE = lib
+    return _PIPE
+
+
+def _paths(paths):
+    arr = (C.c_char_p * len(paths))()
+    arr[:] = [p.encode() for p in paths]
+    return arr
+
+
+def embed_png_batch(ctx, in_paths, out_paths, w, h, bins, headers, payloads, chunk=16, threads=8, png_level=1, center=False, alpha=0.5,
+                    rmin=0.05, rmax=0.45, magmin=0.01, want_usable=True):
+    """tfp_embed_png_batch; returns (usable per file or None, [wall, decode, device, encode] ms)"""
+    lib = load_pipe()
+    n = len(in_paths)
+    headers = np.ascontiguousarray(headers, np.uint8); payloads = np.ascontiguousarray(payloads, np.uint8)
+    assert headers.shape == (n, 38) and payloads.shape[0] == n
+    usable = np.zeros(n, np.uint64) if want_usable else None
+    ms = np.zeros(4, np.float64)
+    rc = lib.tfp_embed_png_batch(ctx.h, n, _paths(in_paths), _paths(out_paths), w, h, int(center), _ptr(bins), len(bins), _ptr(headers), _ptr(payloads),
+                                 payloads.shape[1], alpha, rmin, rmax, magmin, chunk, threads, png_level, _ptr(usable) if want_usable else None, _ptr(ms))
+    _check(rc, "tfp_embed_png_batch")
+    return usable, ms
+
+
+def extract_png_batch(ctx, in_paths, w, h, bins, max_payload_len, chunk=16, threads=8, center=False, alpha=0.5):
+    """tfp_extract_png_batch; returns (headers (n, 38), payloads (n, max_payload_len), status (n,), ms)"""
+    lib = load_pipe()
+    n = len(in_paths)
+    hdr = np.zeros((n, 38), np.uint8); pay = np.zeros((n, max_payload_len), np.uint8); st = np.zeros(n, np.int32); ms = np.zeros(4, np.float64)
+    rc = lib.tfp_extract_png_batch(ctx.h, n, _paths(in_paths), w, h, int(center), _ptr(bins), len(bins), alpha, _ptr(hdr), _ptr(pay), max_payload_len,
+                                   _ptr(st), chunk, threads, _ptr(ms))
+    _check(rc, "tfp_extract_png_batch")
+    return hdr, pay, st, ms
+

@@ -161,7 +161,10 @@ static bool load_rgb8_unchecked(const std::string& path, std::vector<uint8_t>& r
     return false;
 }
 
-bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out) {
+bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out) { return png_encode_rgb8_opt(rgb, w, h, out, 6, true); }
+
+// level: zlib level (1 fastest .. 9); adaptive: per-line filter choice (five trial filters per line) or the fixed "up" filter
+bool png_encode_rgb8_opt(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out, int level, bool adaptive) {
     if (w < 1 || h < 1) return false;
     const size_t stride = (size_t)w * 3;
     std::vector<uint8_t> raw((stride + 1) * h), cand(stride);
@@ -170,7 +173,7 @@ bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out
         const uint8_t* cur = rgb + (size_t)y * stride;
         const uint8_t* prev = y ? rgb + (size_t)(y - 1) * stride : zero.data();
         long best = -1; int bf = 0;
-        for (int ft = 0; ft < 5; ft++) {
+        for (int ft = 0; ft < 5 && adaptive; ft++) {
             long score = 0;
             for (size_t i = 0; i < stride; i++) {
                 const int a = i >= 3 ? cur[i - 3] : 0, b = prev[i], c = i >= 3 ? prev[i - 3] : 0;
@@ -179,6 +182,7 @@ bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out
             }
             if (best < 0 || score < best) { best = score; bf = ft; }
         }
+        if (!adaptive) bf = 2;
         uint8_t* o = &raw[(size_t)y * (stride + 1)];
         o[0] = (uint8_t)bf;
         for (size_t i = 0; i < stride; i++) {
@@ -189,7 +193,7 @@ bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out
     }
     uLongf cl = compressBound((uLong)raw.size());
     std::vector<uint8_t> comp(cl);
-    if (compress2(comp.data(), &cl, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    if (compress2(comp.data(), &cl, raw.data(), (uLong)raw.size(), level < 1 ? 1 : level > 9 ? 9 : level) != Z_OK) return false;
     comp.resize(cl);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     out.assign(sig, sig + 8);

@@ -13,4 +13,5 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& w, int& 
 bool png_decode_rgb8(const uint8_t* data, size_t n, std::vector<uint8_t>& rgb, int& w, int& h);
 bool png_write_rgb8(const std::string& path, const uint8_t* rgb, int w, int h);
 bool png_encode_rgb8(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out);
+bool png_encode_rgb8_opt(const uint8_t* rgb, int w, int h, std::vector<uint8_t>& out, int level, bool adaptive_filter);
 }  // namespace tfh

@@ -140,3 +140,52 @@ def test_nonpow2_behaves_like_the_reference(covers):
     r1 = run(REF_CLI, "extract", "--in", a, "--pass", "p", *IT)
     r2 = run(CLI, "extract", "--in", a, "--pass", "p", *IT)
     assert (r1.returncode, r1.stderr) == (r2.returncode, r2.stderr) == (1, "Magic not found.\n")
+
+
+@pytest.mark.skipif(not have_ref(), reason="reference CLI not present")
+def test_png_pipeline_files_are_read_by_the_reference(tmp_path):
+    """SURVEY 8 f-1 end to end (libtfpipe.so): PNG covers -> inflate threads -> tfft_embed_stream_batch -> deflate threads -> PNG stego
+    files, several chunks deep so that the three stages overlap.  Every file it writes must give its secret back to the REFERENCE CLI
+    (stbi_load + do_extract, S:1112-1312), and tfp_extract_png_batch must return the frames' bytes."""
+    import ctypes as C
+    from steganosaurus_amd import binding as B
+    host = C.CDLL(os.path.join(ROOT, "steganosaurus_amd", "libtfhost.so"))
+    host.tfh_frame_bits.restype = C.c_uint64
+    w = h = 256
+    n = 7
+    secrets = [("pipeline secret #%d " % i + "x" * 10)[:24].encode() for i in range(n)]
+    ins, outs = [], []
+    for i in range(n):
+        img = gradient_cover(w, h, 10 + i)
+        p = str(tmp_path / ("c%d.png" % i))
+        assert host.tfh_png_write(p.encode(), img.ctypes.data_as(C.c_void_p), w, h) == 0
+        ins.append(p); outs.append(str(tmp_path / ("s%d.png" % i)))
+    headers = np.zeros((n, 38), np.uint8); payloads = np.zeros((n, 24 + 16), np.uint8)
+    for i in range(n):
+        salt = bytes((17 * i + j) & 255 for j in range(16))
+        bits = np.zeros(38 * 24 + 40 * 56, np.uint8)
+        got = host.tfh_frame_bits(b"pw1", salt, 1000, secrets[i], len(secrets[i]), bits.ctypes.data_as(C.c_void_p), C.c_uint64(len(bits)))
+        assert got == len(bits)
+        headers[i] = np.packbits(bits[:912].reshape(-1, 3)[:, 0])
+        payloads[i] = np.packbits(bits[912:].reshape(-1, 7)[:, 0])
+    pk = np.zeros(32, np.uint8); sub = np.zeros(128, np.uint8)
+    host.tfh_turtle_subkeys(b"pw1", C.c_size_t(3), pk.ctypes.data_as(C.c_void_p), sub.ctypes.data_as(C.c_void_p))
+    n_bits = 912 + 40 * 56
+    bins = B.Walk(bytes(sub[:32]), h, w).next(int(n_bits * 1.25))
+    ctx = B.Context(w, h, slots=3)
+    usable, ms = B.embed_png_batch(ctx, ins, outs, w, h, bins, headers, payloads, chunk=3, threads=3, png_level=1)
+    assert (usable >= n_bits).all(), usable
+    for i in range(n):
+        r = run(REF_CLI, "extract", "--in", outs[i], "--pass", "pw1", *IT)
+        assert (r.returncode, r.stdout) == (0, secrets[i].decode() + "\n"), (i, r.stderr)
+    hdr, pay, st, ms2 = B.extract_png_batch(ctx, outs, w, h, bins, 40, chunk=3, threads=3)
+    assert (st == 24).all(), st
+    assert np.array_equal(hdr, headers) and np.array_equal(pay, payloads)
+    # and with the CLI's own PNG flavour (adaptive filters, zlib level 6): same pixels
+    outs6 = [o.replace(".png", "_l6.png") for o in outs]
+    B.embed_png_batch(ctx, ins, outs6, w, h, bins, headers, payloads, chunk=4, threads=2, png_level=6)
+    r = run(REF_CLI, "extract", "--in", outs6[n - 1], "--pass", "pw1", *IT)
+    assert (r.returncode, r.stdout) == (0, secrets[n - 1].decode() + "\n")
+    ctx.close()
+    print("png pipeline stage ms [wall, decode, device, encode]:", ms, ms2)
+

@@ -54,6 +54,15 @@ def test_header_symbols_are_exported_and_bound():
     assert set(B.SYMBOLS) <= declared
     assert lib.tfft_abi_version() == 1
     assert b"no CPU fallback" in lib.tfft_strerror(-2)
+    # the PNG pipeline helper (include/turtlefft_pipe.h -> libtfpipe.so)
+    hdr = open(os.path.join(ROOT, "include", "turtlefft_pipe.h")).read()
+    declared = set(re.findall(r"\b(tfp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {"tfp_embed_png_batch", "tfp_extract_png_batch"}
+    exported = subprocess.run(["nm", "-D", "--defined-only", os.path.join(PKG, "libtfpipe.so")], capture_output=True, text=True, check=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, exported), name
+    pipe = B.load_pipe()
+    assert pipe.tfp_embed_png_batch and pipe.tfp_extract_png_batch
 
 
 def test_no_gpu_means_loud_failure():
