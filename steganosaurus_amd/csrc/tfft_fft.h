@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace tfft {
 
 // Complex arithmetic on native 2-vectors: (re, im) stays ONE 64-bit register pair through the optimiser, so an add is one
@@ -267,12 +269,44 @@ __device__ __forceinline__ void fft_block(float2 (&u)[E], float2* lds, const Lay
 // kernels whose occupancy is limited by VGPRs rather than by table latency.
 //   active (uniform over the threads that share a sequence): false = this thread's sequence does not exist (a padded
 //   row); it computes nothing and touches no LDS but still takes part in the workgroup barriers of BlockSync.
+// Cross-lane form of ONE exchange (-DTFFT_XLANE=0: through LDS like the others): in the 1024-point transform of one wave
+// (T = 64, E = 16) the exchange between the second radix-16 pass and the final radix-4 pass is a 4 x 4 transpose between the
+// wave's four 16-lane rows and four registers -- lane (g, l) holds outputs s = a + 4q in registers, lane (r, l) needs register a = r of
+// lane group g = ... -- which gfx950 does in registers with v_permlane16_swap / v_permlane32_swap (8 instructions per complex 4 x 4
+// block) instead of 16 ds_write_b64 + 16 ds_read_b64 and two wave syncs.  Measured on one box (round 3, gpurun_out/r3n, 32 x 1080p):
+// SQ_INSTS_LDS -18 .. -22 %, SQ_INSTS_VALU -2 .. -3 % (the address arithmetic of the LDS operations was more than the 32 swaps),
+// fused forward 282.7 / 111.6 -> 282.1 / 107.3 us, fused inverse 472.9 -> 468.3 us, step 2.928 -> 2.919 and 3.030 -> 3.002 ms.
+// (The FIRST exchange of that transform is a 16 x 16 transpose between the low lane nibble and the register index: ~128 swaps
+// and selects, not tried; rows of two waves exchange across waves and need LDS anyway.)
+#ifndef TFFT_XLANE
+#define TFFT_XLANE 1
+#endif
+#if defined(__HIPCC__) && TFFT_XLANE
+__device__ __forceinline__ void xl_swap16(float& x, float& y) {     // odd 16-lane rows of x <-> even rows of y
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xl_swap32(float& x, float& y) {     // upper 32 lanes of x <-> lower 32 lanes of y
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xl_transpose4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    xl_swap16(a0.x, a1.x); xl_swap16(a0.y, a1.y); xl_swap16(a2.x, a3.x); xl_swap16(a2.y, a3.y);
+    xl_swap32(a0.x, a2.x); xl_swap32(a0.y, a2.y); xl_swap32(a1.x, a3.x); xl_swap32(a1.y, a3.y);
+}
+#define TFFT_XLANE_ON 1
+#else
+#define TFFT_XLANE_ON 0
+#endif
+
 template <int N, int E, int SIGN, int P, class Lay, class Sync>
 struct FftPassesLazy {
     static constexpr int R = imin(E, N / P);
     static constexpr bool LAST = (P * R == N);
     static constexpr int T = N / E;
     static constexpr int Q = E / R;
+    // the exchange after this pass done in registers across lanes (see above)
+    static constexpr bool XL = TFFT_XLANE_ON && std::is_same<Sync, WaveSync>::value && N == 1024 && E == 16 && P == 16;
     static __device__ __forceinline__ void run(float2 (&u)[E], float2* lds, const Lay& lay, int t, int b,
                                                const float2* __restrict__ tw, int tws, bool active) {
         float2 o[E];
@@ -290,7 +324,7 @@ struct FftPassesLazy {
                     for (int r = 1; r < R; r++) v[r] = cmul(v[r], twload<SIGN>(tw, r * base));
                 }
                 DftReg<R, SIGN, 0, R>::run(v);
-                if constexpr (LAST) {
+                if constexpr (LAST || XL) {
 #pragma unroll
                     for (int s = 0; s < R; s++) o[q + s * Q] = v[bitrev(s, ilog2(R))];
                 } else {
@@ -305,6 +339,18 @@ struct FftPassesLazy {
 #pragma unroll
                 for (int m = 0; m < E; m++) u[m] = o[m];
             }
+        } else if constexpr (XL) {
+#if TFFT_XLANE_ON
+            if (active) {           // wave uniform: the wave is the row
+#pragma unroll
+                for (int q2 = 0; q2 < 4; q2++) xl_transpose4(o[4 * q2], o[4 * q2 + 1], o[4 * q2 + 2], o[4 * q2 + 3]);
+#pragma unroll
+                for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[q2 + 4 * r] = o[r + 4 * q2];
+            }
+#endif
+            FftPassesLazy<N, E, SIGN, P * R, Lay, Sync>::run(u, lds, lay, t, b, tw, tws, active);
         } else {
             Sync::sync();
             if (active) {
