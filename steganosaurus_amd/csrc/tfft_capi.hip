@@ -55,6 +55,11 @@ struct tfft_ctx {
     float2* spec_pool = nullptr;
     float2* tmp_pool = nullptr;
     unsigned* cand_pool = nullptr;
+    float2* mini_pool = nullptr;          // [n_slots*3*max_ph*mini_cols] the sample of column tiles the tile statistics guess their bracket from
+    size_t mini_cols = 0;
+    int stats_tile = 1;                   // batched delta embeds run the statistics' bracket pass inside the last forward column step and never store
+                                          // the spectrum or |F|^2 (TFFT_STATS_TILE=0: |F|^2 planes + the statistics kernels over them, round 2's default)
+    int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
     float2* col0_pool = nullptr;          // [n_slots*3*max_ph] the packed column 0 of batched embeds that store |F|^2 planes (ColParams::st_col0)
     int stats_skew = 0;                   // test hook (TFFT_STATS_SKEW): brackets moved by this many buckets -- the fast path fails, the fallbacks run
     SelectState* sel = nullptr;           // [n_slots*3]
@@ -210,7 +215,13 @@ void invalidate_graphs(tfft_ctx* c);      // cached launch sequences hold raw de
 static void copy_embed_fields(ColParams& cp, const ColParams& e) {
     cp.rd_bins = e.rd_bins; cp.rd_off = e.rd_off; cp.trash = e.trash;
     cp.em_n = e.em_n; cp.em_cos = e.em_cos; cp.em_sin = e.em_sin; cp.em_fl = e.em_fl; cp.em_pb = e.em_pb; cp.em_on = 1; cp.em_m2 = e.em_m2;
-    cp.st_col0 = e.st_col0;
+    cp.st_sel = e.st_sel; cp.st_cand = e.st_cand; cp.st_cand_stride = e.st_cand_stride; cp.st_partial = e.st_partial; cp.st_amb = e.st_amb;
+    cp.st_col0 = e.st_col0; cp.st_slo = e.st_slo; cp.st_shi = e.st_shi; cp.st_cap = e.st_cap; cp.st_PW = e.st_PW;
+}
+
+static void copy_plain_extra(ColParams& cp, const ColParams& e) {
+    if (e.tile_step > 1) cp.tiles_per_block = 1;      // the sample: an eighth of the tiles, one per workgroup keeps the grid wide
+    cp.tile_step = e.tile_step; cp.tile_off = e.tile_off; cp.out_M = e.out_M; cp.out_plane_stride = e.out_plane_stride; cp.out_img_stride = e.out_img_stride; cp.gate = e.gate;
 }
 
 // How a launch sequence wants the outer column steps and the inverse row kernel to run: handed down explicitly per call (until round 3
@@ -221,6 +232,8 @@ struct StageMode {
     const int* fwd_last_row = nullptr;     // the last forward column step stores rows <= *fwd_last_row only (COLS_ROWLIMIT)
     const ColParams* inv_embed = nullptr;  // the first inverse column step runs in COLS_EMBED mode (delta embedding) with these rd_*/em_* fields
     const uint8_t* inv_cover = nullptr;    // ... and the inverse row kernel adds its transform to these cover pixels
+    const ColParams* fwd_plain_extra = nullptr;   // plain last forward step: tile_step / out_* (the statistics' sample) or gate fields, and ...
+    float2* fwd_out_override = nullptr;           // ... its output buffer
 };
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st, const StageMode& md = StageMode()) {
@@ -255,7 +268,8 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             }
                 if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
                 else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
-                HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+                else if (md.fwd_plain_extra) copy_plain_extra(cp, *md.fwd_plain_extra);
+                HIPCHK(c, launch_cols(tmp, md.fwd_out_override ? md.fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
                 cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.H; cp.out_rows = s.PH; cp.tw_out = 1;
                 HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, +1, 3 * n, st));
@@ -272,7 +286,8 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
             }
             if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
             else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
-            HIPCHK(c, launch_cols(tmp, spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
+                else if (md.fwd_plain_extra) copy_plain_extra(cp, *md.fwd_plain_extra);
+            HIPCHK(c, launch_cols(tmp, md.fwd_out_override ? md.fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
         case COLS_INV_A:
             if (pl.direct) {
@@ -551,6 +566,8 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_COMPACT")) c->stats_compact = atoi(e);
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_EXACT_STATS")) c->exact_stats = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
@@ -561,13 +578,16 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     c->slots.resize(n_slots);
     const size_t M = (size_t)pw / 2;
     c->slot_stride = 3 * (size_t)ph * M;
-    c->cand_stride = (size_t)ph * (M + 1);
+    // one slot per value of a plane (PH*(M+1)) + the slack of COLS_STAT's per-wave reservations (TFFT_STAT_RESV slots at a time: < 19 % even
+    // when every value is a candidate)
+    c->cand_stride = (size_t)ph * (M + 1) + (size_t)ph * M / 4 + 256;
     c->img_stride_b = (((size_t)max_w * max_h * 3 + 255) / 256) * 256;
     const size_t ns = (size_t)n_slots;
     int rc = dev_alloc(c, (void**)&c->img_pool, ns * c->img_stride_b + 256);
     if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
+    c->mini_cols = (size_t)(next_pow2(max_w) < 2 ? 1 : next_pow2(max_w) / 2) / 8 + 16;          // (mini_pool itself is allocated by the first call that uses the tile statistics)
     if (!rc) rc = dev_alloc(c, (void**)&c->col0_pool, ns * 3 * (size_t)ph * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
@@ -591,7 +611,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipDeviceSynchronize();
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->col0_pool);
+    (void)hipFree(c->mini_pool); (void)hipFree(c->col0_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->ex_cand); (void)hipFree(c->ex_val); (void)hipFree(c->ex_below); (void)hipFree(c->ex_n); for (auto& kv : c->ex_table) (void)hipFree(kv.second); (void)hipFree(c->trash); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
@@ -1048,6 +1068,71 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 }
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
+// forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
+// phases (tfft_profile_stage times them apart): 1 the steps before the last column step, 2 sample + bracket guess, 4 the COLS_STAT step,
+// 8 select + gated spectrum + fallbacks + capacity
+static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, hipStream_t st, ColParams& em, const CapParams& cap,
+                                     unsigned long long* usable, int phases = 15) {
+    const Slot& s = c->slots[s0];
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+    const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
+    // the sample: column tiles off, off + step, ..  -- centred in their strides (tiles 0, step, .. sit at the low-frequency end of every
+    // stride and read a median several per cent too high: the bracket missed on every padded image)
+    const int M = s.PWi / 2, ntiles = (M + 15) / 16, step = c->stats_tile_step;
+    const int off = ntiles > step / 2 ? step / 2 : 0;
+    const int Ms = 16 * ((ntiles - off + step - 1) / step);
+    if ((size_t)Ms > c->mini_cols) return TFFT_E_STATE;
+    if (!c->mini_pool) {
+        (void)hipStreamSynchronize(c->stream);
+        invalidate_graphs(c);
+        if (dev_alloc(c, (void**)&c->mini_pool, (size_t)c->n_slots * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols * sizeof(float2))) return TFFT_E_NOMEM;
+    }
+    int rc;
+    for (int stage : {ROWS_FWD, COLS_FWD_A}) {
+        if (stage == final_fwd || !(phases & 1)) break;
+        rc = enqueue_fft_stage(c, s0, g, stage, rgb_in, nullptr, st);
+        if (rc) return rc;
+    }
+    float2* mini = c->mini_pool + (size_t)s0 * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols;
+    float2* col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
+    SelectState* sel = c->sel + 3 * s0;
+    unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
+    float* amb = c->amb + (size_t)3 * s0 * TFFT_AMB_CAP;
+    unsigned* cand = c->cand_pool + (size_t)3 * s0 * c->cand_stride;
+    // (1) every step-th column tile -> a narrow spectrum; its histogram brackets the medians
+    ColParams ex{};
+    ex.tile_step = step; ex.tile_off = off; ex.out_M = Ms; ex.out_plane_stride = (size_t)s.PH * Ms; ex.out_img_stride = (size_t)3 * s.PH * Ms;
+    if (phases & 2) {
+        StageMode ms;
+        ms.fwd_plain_extra = &ex; ms.fwd_out_override = mini;
+        rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st, ms);
+        if (rc) return rc;
+        HIPCHK(c, launch_stat_guess(mini, s.PH, s.PWi, Ms, ex.out_img_stride, g, sel, &cap, partial, off == 0 ? 1 : 0, st));
+        if (c->stats_skew) HIPCHK(c, launch_skew_bracket(sel, g, c->stats_skew, st));
+    }
+    // (2) the last forward step: values of the listed bins + the bracket pass on every value
+    if (phases & 4) {
+    em.st_sel = sel; em.st_cand = cand; em.st_cand_stride = c->cand_stride; em.st_partial = partial; em.st_amb = amb; em.st_col0 = col0;
+    em.st_slo = cap.s_lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_lo; em.st_shi = cap.s_hi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)cap.s_hi;
+    em.st_cap = 1; em.st_PW = cap.PW;
+    { StageMode me; me.fwd_emit = &em;
+      rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st, me); }
+    em.st_sel = nullptr;
+    if (rc) return rc;
+    }
+    if (!(phases & 8)) return TFFT_OK;
+    HIPCHK(c, launch_stat_select(s.PH, g, sel, cand, c->cand_stride, c->med + 3 * s0, col0, st));
+    // (3) images with a plane the fast path could not settle: their spectrum after all (the others return at once), then the fallbacks
+    ColParams gt{};
+    gt.gate = sel;
+    { StageMode mg; mg.fwd_plain_extra = &gt;
+      rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st, mg); }
+    if (rc) return rc;
+    HIPCHK(c, launch_stat_settle(c->spec(s0), s.PH, s.PWi, c->slot_stride, g, sel, c->med + 3 * s0, &cap, partial, amb, usable, st));
+    for (int i = 0; i < g; i++) { c->slots[s0 + i].has_spec = false; c->slots[s0 + i].rgb_src = nullptr; }
+    return TFFT_OK;
+}
+
 struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
@@ -1085,6 +1170,24 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         // the stream bits in bucket order (the packed frames of the stream pipelines are expanded on the way).  (On the side stream
         // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
+    }
+    if (delta && usable && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback) {
+        // the statistics' bracket pass inside the last forward column step: neither the spectrum nor |F|^2 is stored (unless a plane's
+        // bracket turns out wrong: then the gated plain step produces the spectrum for the fallback kernels)
+        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+        CapParams p = cap_params(c, s, rmin, rmax);
+        p.magmin = magmin;
+        // (tall grids, whose annulus reaches the mirror half beyond column PW/2, keep the |F|^2 planes: COLS_STAT counts stored bins only)
+        const unsigned long long mirror_d = (unsigned long long)(p.PW - s.PWi / 2) * (unsigned long long)(p.PW - s.PWi / 2);
+        if (p.bw > 0 && p.s_lo <= p.s_hi && p.s_hi < 0xFFFFFFFFull && mirror_d > p.s_hi && !pl.direct && pl.log_n2 >= 4 && pl.log_n2 <= 9 &&
+            (unsigned long long)s.PH * s.PWi <= (1ull << 24) && (s.PWi / 2) % 16 == 0) {
+            em.em_m2 = 0;
+            rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable);
+            if (rc) return rc;
+            StageMode mi;
+            mi.inv_embed = &em; mi.inv_cover = rgb_in;
+            return enqueue_inverse(c, s0, g, rgb_out, st, mi);
+        }
     }
     StageMode md;
     if (delta) md.fwd_emit = &em;

@@ -47,8 +47,21 @@ struct ColParams {
     const uint8_t* em_pb;            // COLS_EMBED: em_n stream bits per image in the same order (k_gather_bits; 2 = not written)
     uint64_t em_n;                   // list stride between images (the length of the bin list)
     float em_cos, em_sin;
-    float2* st_col0;                 // COLS_EMIT with em_m2: per (image, plane) PH values, the packed column 0 (its two real spectra cannot be
-                                     // separated from magnitudes, so it travels beside the |F|^2 plane)
+    // statistics inside the last forward step (COLS_STAT = COLS_EMIT without the spectrum store): every value is classified against
+    // the bracket of its plane's SelectState exactly as k_collect_bracket does (weight below, candidates, capacity counts, parked
+    // values); the packed column 0 goes to st_col0 for k_col0_stats
+    struct SelectState* st_sel;      // 3 per image
+    unsigned* st_cand; size_t st_cand_stride;
+    unsigned st_cand_fixed;     // COLS_STAT: slots at the head of a plane's list owned by the launch's waves (set by the launcher); appended entries follow
+    unsigned* st_partial;            // per (image, plane) TFFT_STAT_MAX_BLOCKS counters (a workgroup adds to slot block % that)
+    float* st_amb;
+    float2* st_col0;                 // per (image, plane) PH values
+    unsigned st_slo, st_shi;         // squared radius bounds of the annulus, clamped to 32 bits
+    int st_cap, st_PW;
+    // forward COLS_PLAIN only: a sample of the tiles (0, tile_step, 2*tile_step, ..) written side by side into a narrow spectrum
+    int tile_step, tile_off; int out_M; size_t out_plane_stride, out_img_stride;      // tiles tile_off + i*tile_step
+    // forward COLS_PLAIN only: images whose statistics were settled without the spectrum (all three planes) return at once
+    const struct SelectState* gate;
     int em_on;
     // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
     // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off
@@ -135,9 +148,10 @@ struct SelectState {        // one per (image, plane)
     // never, the few in between are parked (their |F|^2, once per full-grid bin) and settled by k_capacity_settle
     float t2_lo, t2_hi;
     unsigned n_amb;             // parked values (may exceed TFFT_AMB_CAP: then the plane falls back to k_capacity)
-    unsigned cap_pad;
+    unsigned cand_fixed;        // slots at the head of the candidate list owned by COLS_STAT's waves (holes included); appended entries follow
 };
 #define TFFT_AMB_CAP 8192
+#define TFFT_CAND_HOLE 0x7FFFFFFFu      // an unused slot of the candidate list (COLS_STAT reserves slots per wave): weight bit clear, a value no bracket reaches
 
 hipError_t launch_rows_fwd(const uint8_t* rgb, float2* out, const float2* tw_pw, const RowParams& P, int n_images,
                            hipStream_t s);
@@ -157,6 +171,12 @@ hipError_t audit_load_rgb8_f64(const uint8_t* rgb_dev, int W, int H, int PW, int
 hipError_t launch_bucket_bins(const tfft_bin* bins, const uint32_t* bit_index, uint64_t n, int PH, int PW, int G,
                               unsigned* cnt, unsigned* off, TileBin* out, int* err, int force_global, hipStream_t s);
 // highest stored row any bin of the list touches -> *last_row (device int, reset here)
+hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t mini_img_stride, int n_images, SelectState* st, const struct CapParams* cap,
+                             unsigned* partial, int col0_packed, hipStream_t s);
+hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s);
+hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s);
+hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st, float* med_out, const struct CapParams* cap,
+                              unsigned* partial, float* amb, unsigned long long* usable, hipStream_t s);
 hipError_t launch_gather_bits(const TileBin* ent, const unsigned* n_ent, const uint8_t* bits, const uint8_t* hdr, const uint8_t* pay, uint64_t plen,
                               uint64_t n, uint64_t limit, int n_images, uint8_t* out, hipStream_t s);
 hipError_t launch_bins_last_row(const tfft_bin* bins, uint64_t n, int PH, int PW, int* last_row, hipStream_t s);

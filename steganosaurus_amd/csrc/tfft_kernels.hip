@@ -886,9 +886,12 @@ __device__ __forceinline__ int read_bit_value(float2 v, const EmbedParams& P, in
 //                  bucketed to it (F read from `in` at those bins only) and is transformed: the stego image is cover + IFFT(F' - F),
 //                  so neither k_embed's scattered read-modify-write nor this step's read of the whole spectrum takes place
 //   COLS_EMIT      delta embedding (last forward step): the transform, plus the values of the listed bins written to P.em_fl
-// (round 2 also had COLS_STAT: COLS_EMIT without the spectrum store, the statistics' bracket pass done on the parked tile.  Identical
-//  results, measured slower -- 3.41 vs 3.30 ms per 32 x 1080p round trip, 4.42 vs 4.30 per 8 x 4K -- and removed in round 3.)
-enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4 };
+//   COLS_STAT      COLS_EMIT without any spectrum store: the statistics' bracket pass (weight below the median's bracket, its members,
+//                  the capacity counts against the threshold's bracket) runs on the values in registers (ColParams::st_*).  Round 2
+//                  built this on the parked tile, measured it slower and shelved it; on round 3's kernels (two workgroups per CU,
+//                  no 64-byte |F|^2 stores to wait for) the step itself gets FASTER by it and the |F|^2 plane, its write and the
+//                  bracket pass over it disappear
+enum { COLS_PLAIN = 0, COLS_ROWLIMIT = 1, COLS_READ = 2, COLS_EMBED = 3, COLS_EMIT = 4, COLS_STAT = 5 };
 __device__ __forceinline__ unsigned wave_rank_of(unsigned long long m) {       // rank of this lane among the set bits of a wave mask
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -913,8 +916,16 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // A workgroup walks `tiles_per_block` adjacent 16-column tiles.  The twiddles depend on (t, g) only,
     // so they are fetched once; the next tile's data is fetched into registers while the current tile
     // is being transformed (the loads of tile i+1 overlap the LDS exchanges and stores of tile i).
+    if (MODE == COLS_PLAIN && SIGN > 0 && P.gate) {      // the statistics of this image were settled without the spectrum: nothing to redo
+        const SelectState* gs = P.gate + 3 * img;
+        if (gs[0].fast && gs[1].fast && gs[2].fast && gs[0].n_amb <= TFFT_AMB_CAP && gs[1].n_amb <= TFFT_AMB_CAP && gs[2].n_amb <= TFFT_AMB_CAP) return;
+    }
+    // COLS_PLAIN forward with tile_step > 1 (the statistics' sample): tile index i stands for tile i*tile_step + tile_off of the input
+    // and for column block i of a narrow output (out_M columns)
+    const int ts = (MODE == COLS_PLAIN && SIGN > 0 && P.tile_step > 1) ? P.tile_step : 1;
+    const int toff = ts > 1 ? P.tile_off : 0;
     const int tile0 = blockIdx.x * P.tiles_per_block;
-    const int ntiles = (P.M + C - 1) / C;
+    const int ntiles = ((P.M + C - 1) / C - toff + ts - 1) / ts;
     const int tile1 = (tile0 + P.tiles_per_block < ntiles) ? tile0 + P.tiles_per_block : ntiles;
     // The loads of a tile are UNCONDITIONAL at clamped (always valid) addresses; elements that do not exist (rows >= in_rows, the
     // columns / groups beyond the grid) are zeroed by tile_mask() when the tile is consumed.  Written as `cond ? src[i] : 0` every
@@ -933,18 +944,19 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     const unsigned voff_in = (unsigned)((P.in_a * t + P.in_b * g) * P.M + c) * 8u;
     const size_t stride_in = (size_t)P.in_a * T * P.M * sizeof(float2);
     const char* in_bytes = reinterpret_cast<const char*>(in + plane_off);
-    const unsigned voff_out = (unsigned)((P.out_a * t + P.out_b * g) * P.M + c) * 8u;
-    const size_t stride_out = (size_t)P.out_a * T * P.M * sizeof(float2);
-    char* out_bytes = reinterpret_cast<char*>(out + plane_off);
+    const int oM = ts > 1 ? P.out_M : P.M;
+    const unsigned voff_out = (unsigned)((P.out_a * t + P.out_b * g) * oM + c) * 8u;
+    const size_t stride_out = (size_t)P.out_a * T * oM * sizeof(float2);
+    char* out_bytes = reinterpret_cast<char*>(out + (ts > 1 ? (size_t)img * P.out_img_stride + (size_t)plane * P.out_plane_stride : plane_off));
     char* m2_bytes = reinterpret_cast<char*>(reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride);      // COLS_EMIT: the |F|^2 plane
     auto load_tile = [&](int tile, float2 (&v)[E]) {
         if (in_full) {
-            const char* tb = in_bytes + (size_t)tile * (C * sizeof(float2));
+            const char* tb = in_bytes + (size_t)(imin(tile, ntiles - 1) * ts + toff) * (C * sizeof(float2));      // (a workgroup past the last tile loads it again)
             const unsigned vo = opaque_u32(voff_in);
 #pragma unroll
             for (int m = 0; m < E; m++) v[m] = *reinterpret_cast<const float2*>(tb + m * stride_in + vo);
         } else {
-            const int col = imin(tile * C + c, P.M - 1);
+            const int col = imin((tile * ts + toff) * C + c, P.M - 1);
             const float2* src = in + plane_off;
             const int gc = imin(g, P.G - 1), to = (int)opaque_u32((unsigned)t);
 #pragma unroll
@@ -956,7 +968,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     };
     auto tile_mask = [&](int tile, float2 (&v)[E]) {       // workgroup-uniform test first: the final steps never need it
         if (in_full) return;
-        const bool active = (tile * C + c < P.M) && (g < P.G);
+        const bool active = ((tile * ts + toff) * C + c < P.M) && (g < P.G);
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const int row = P.in_a * (t + m * T) + P.in_b * g;
@@ -968,7 +980,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // c*A_W of the tile's column travels with the tile's loads (fetched where it is used it sat behind the prefetch of
     // the next tile in the in-order vmcnt queue and cost the overlap: 0.60 -> 0.87 ms)
     float2 awc = make_float2(0.f, 0.f), awn = make_float2(0.f, 0.f);
-    auto load_aw = [&](int tile) -> float2 { const int col = tile * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
+    auto load_aw = [&](int tile) -> float2 { const int col = (tile * ts + toff) * C + c; return (DC && col < P.M) ? P.dc_aw[col] : make_float2(0.f, 0.f); };
     // the first tile's loads go out before anything else: the tables staged below (each a global -> LDS round trip) ride behind them,
     // and ONE barrier at the end of the prologue covers them all
     if (PF) { load_tile(tile0, u); awc = load_aw(tile0); }
@@ -1017,6 +1029,12 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // 4K bucket (a longer one fetches the rest in place, a dependent round trip in the middle of the tile): first inverse step
     // 0.547 -> 0.512 ms per 8 x 4K launch (round 3, gpurun_out/r3f; round 2's kernel, one workgroup per CU at 247 registers, lost by it)
 #ifndef TFFT_EMBED_NE9
+#ifndef TFFT_STAT_RESV
+#define TFFT_STAT_RESV 192      // slots of the candidate list a wave reserves at a time
+#endif
+#ifndef TFFT_STAT_SLOTS
+#define TFFT_STAT_SLOTS 193     // staged candidates per wave (+ one spare slot), flushed once per tile
+#endif
 #define TFFT_EMBED_NE9 4
 #endif
     constexpr int NE = (LOGL >= 9) ? (MODE == COLS_EMBED ? (LOGL == 9 ? TFFT_EMBED_NE9 : 2) : 4) : 2;
@@ -1027,7 +1045,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // the bucket offsets of the workgroup's tiles (at most NOFF: the launcher sees to it) sit in LDS: read with lgkmcnt, not vmcnt,
     // and without the branch trees a register array indexed by the tile turned into
     unsigned* lds_eo = reinterpret_cast<unsigned*>(lds_tw + (TWL ? L : 0) + blockDim.z * C) + gl * (NOFF + 2);
-    if (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT) {
+    if (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT) {
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
         for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
     }
@@ -1063,18 +1081,67 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
         if (conj) nv = cconj(nv);
         return csub(nv, f);
     };
+    // ---- COLS_STAT: k_collect_bracket's per-value work (see there) on this kernel's registers.  Candidates are staged per wave in LDS
+    // (128 slots behind the bucket offsets; flushed with one global atomic once more than 64 are waiting: a value adds at most 64)
+    const int st_lin = (gl * T + t) * C + c, st_wave = st_lin >> 6;
+    unsigned* st_wbuf = lds_eo + (blockDim.z - gl) * (NOFF + 2) + st_wave * TFFT_STAT_SLOTS;
+    unsigned* st_wcnt = lds_eo + (blockDim.z - gl) * (NOFF + 2) + ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6) * TFFT_STAT_SLOTS;      // [0], [1]: the workgroup's sums, [2 + wave]: a wave's list base
+    SelectState* st_s = (MODE == COLS_STAT) ? P.st_sel + 3 * img + plane : nullptr;
+    const unsigned st_lo = (MODE == COLS_STAT) ? st_s->lo : 0u, st_span = (MODE == COLS_STAT) ? st_s->hi - st_lo : 0u, st_base = st_lo << 19;
+    // (thresholds clamped at 0 -- mag2_threshold answers -inf for "everything passes", |F|^2 is never negative -- so that -1 can stand for
+    // "not a bin of the annulus" in the comparisons below)
+    const float st_t2lo = (MODE == COLS_STAT) ? fmaxf(st_s->t2_lo, 0.f) : 0.f, st_t2hi = (MODE == COLS_STAT) ? fmaxf(st_s->t2_hi, 0.f) : 0.f;
+    unsigned* st_out = (MODE == COLS_STAT) ? P.st_cand + ((size_t)img * 3 + plane) * P.st_cand_stride : nullptr;
+    float* st_ambo = (MODE == COLS_STAT) ? P.st_amb + ((size_t)img * 3 + plane) * TFFT_AMB_CAP : nullptr;
+    // per-lane counters (one LDS atomic each at the end).  The classification is written for the VECTOR unit: a compare + add-with-carry
+    // per counter and two branches on VCC per value.  Its first form counted with ballots and scalar popcounts: 39 scalar
+    // instructions per value, and the scalar unit is shared by the CU's four SIMDs -- 0.21 ms of a 1080p batch's 0.66 (round 3).
+    unsigned st_below = 0, st_capcount = 0, st_nstaged = 0;
+    // bucket in [lo, hi] <=> bits - st_base <= st_span_b; never beyond +inf, so that a negative value (column 0's stand-in) stays outside
+    const unsigned st_span_raw = st_span >= 8192u ? 0xFFFFFFFFu : ((st_span << 19) | 0x7FFFFu);
+    const unsigned st_span_b = st_base > 0x7F800000u ? 0u : (st_span_raw < 0x7F800000u - st_base ? st_span_raw : 0x7F800000u - st_base);
+    const unsigned st_aspan = (MODE == COLS_STAT && P.st_shi >= P.st_slo) ? P.st_shi - P.st_slo : 0u;       // annulus: d1 - s_lo <= st_aspan
+    const unsigned st_t2lo_b = __float_as_uint(st_t2lo), st_t2win = __float_as_uint(st_t2hi) - st_t2lo_b;  // threshold window on the bits (values >= 0)
+    // Every wave of the launch owns TFFT_STAT_RESV slots at the head of the plane's candidate list (wave w of workgroup b: slots
+    // (b * nwaves + w) * RESV ..), fills what it does not use with TFFT_CAND_HOLE at the end (the select kernels skip those), and only a
+    // wave with more candidates than that appends the rest behind the fixed part with a global atomic.  (First form: one atomic per
+    // flush, whose round trip the wave sat out -- ~0.1 ms of a 1080p batch's 0.68; reserving with one atomic per wave at the start was
+    // worse still, 0.99: a thousand waves per plane queue on one address at once.)
+    unsigned* st_region = st_out + (size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6)) + st_wave) * TFFT_STAT_RESV;
+    if (MODE == COLS_STAT && blockIdx.x == 0 && blockIdx.y == 0 && st_lin == 0) st_s->cand_fixed = P.st_cand_fixed;
+    unsigned st_used = 0;
+    auto st_fill = [&]() {              // wave uniform
+        for (unsigned i = st_used + (st_lin & 63); i < (unsigned)TFFT_STAT_RESV; i += 64) st_region[i] = TFFT_CAND_HOLE;
+    };
+    auto st_flush = [&]() {             // wave uniform: the wave's staged candidates go to its slots of the plane's list
+        const unsigned lane = st_lin & 63;
+        WaveSync::sync();
+        const unsigned room = (unsigned)TFFT_STAT_RESV - st_used, n1 = st_nstaged < room ? st_nstaged : room;
+        for (unsigned i = lane; i < n1; i += 64) st_region[st_used + i] = st_wbuf[i];
+        st_used += n1;
+        if (st_nstaged > n1) {            // rare: behind the fixed part, as k_col0_stats appends its own
+            const unsigned rest = st_nstaged - n1;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&st_s->n_cand, rest);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((size_t)P.st_cand_fixed + base + rest <= P.st_cand_stride)       // (the list is sized for the worst case, tfft_capi.hip: never false)
+                for (unsigned i = lane; i < rest; i += 64) st_out[(size_t)P.st_cand_fixed + base + i] = st_wbuf[n1 + i];
+        }
+        WaveSync::sync();
+        st_nstaged = 0;
+    };
     if (MODE == COLS_EMBED) em_entries(tile0, enC, true);
-    if (PF && (MODE == COLS_EMIT || MODE == COLS_READ)) em_entries(tile0, enC, false);
+    if (PF && (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ)) em_entries(tile0, enC, false);
     for (int tile = tile0; tile < tile1; tile++) {
         if (!PF && MODE != COLS_EMBED) {      // no prefetch: this tile's loads and list entries now; another resident workgroup covers the wait
             if (!has_bins(tile)) continue;
             load_tile(tile, u); awc = load_aw(tile);
-            if (MODE == COLS_EMIT || MODE == COLS_READ) em_entries(tile, enC, false);
+            if (MODE == COLS_EMIT || MODE == COLS_READ) em_entries(tile, enC, false);      // (COLS_STAT: after its classification, the registers are needed there)
         }
         // the next tile's loads ALWAYS go out (a load inside a branch cannot be counted by s_waitcnt: every later wait would drain the
         // queue): past the last tile, or when the next tile has no bins to read, this tile is fetched again (cache resident, never used)
         if (PF) { const int nt = (tile + 1 < tile1 && has_bins(tile + 1)) ? tile + 1 : tile; load_tile(nt, un); awn = load_aw(nt); }
-        if (PF && (MODE == COLS_EMIT || MODE == COLS_READ)) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
+        if (PF && (MODE == COLS_EMIT || MODE == COLS_STAT || MODE == COLS_READ)) em_entries(tile + 1, enN, false);          // travels with the next tile's loads
         if (MODE == COLS_EMBED) {
             // the tile of F' - F: zeros but for the bins of the list (S:712-732 per bin); a tile without bins is stored as zeros.
             // The values of tile+1's bins and the entries of tile+2 are fetched now (see em_* above the loop).
@@ -1105,7 +1172,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                 if (TWL) fft_block_lazy<L, E, SIGN>(u, lds, lay, t, c, lds_tw, 1);
                 else fft_block<L, E, SIGN>(u, lds, lay, t, c, W);
             }
-            const int col = tile * C + c;
+                const int col = tile * C + c;
             if (FULL) {
                 char* ob = out_bytes + (size_t)tile * (C * sizeof(float2));
                 const unsigned vo = opaque_u32(voff_out);
@@ -1187,6 +1254,43 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
             continue;
         }
         const int col = tile * C + c;
+        // COLS_STAT: the bracket pass of the statistics (k_collect_bracket's classify / cap_elem) on the thread's values while they are in
+        // registers -- unrolled beside the DC term, sixteen independent chains.  (Read back from the parked tile in a rolled loop the same
+        // work cost 210 us of a 1080p batch's 690: one LDS round trip + a dependent chain per value, four waves per SIMD to hide it.)
+        // One value = one stored bin (row, col) of weight 2; the packed column 0 is left to k_col0_stats.
+        // (the launcher only picks this mode when the annulus stays left of column PW/2: the mirror bins of the stored half never count)
+        const bool st_valid = col != 0;
+        // (st_row0 opaque: the rows do not depend on the tile, and left visible the compiler computes every row's square and the
+        // axis tests once before the tile loop -- 50 spilled dwords -- instead of two instructions per value inside it)
+        const unsigned st_col2 = (unsigned)col * (unsigned)col, st_rstep = (unsigned)(P.out_a * T), st_row0 = opaque_u32((unsigned)(P.out_a * t + P.out_b * g));
+#ifndef TFFT_STAT_CUT
+#define TFFT_STAT_CUT 0      // measurement builds only
+#endif
+        unsigned st_ambflag = 0;
+        auto st_value = [&](int m, float2 v) {
+#if TFFT_STAT_CUT & 8
+            st_capcount += (v.x > 1e30f) ? 1u : 0u; return;      // measurement build: the value is used, nothing else
+#endif
+            const float m2 = st_valid ? fmaf(v.x, v.x, v.y * v.y) : -1.0f;
+            const unsigned b = __float_as_uint(m2), rel = b - st_base, row = st_row0 + (unsigned)m * st_rstep;
+            // median: values below the bracket are counted, values inside it staged for the select (lanes without one write the spare slot)
+            st_below += (b < st_base) ? 1u : 0u;
+            const bool cnd = rel <= st_span_b && !(TFFT_STAT_CUT & 32);
+            const unsigned long long mk = __ballot(cnd);
+            {   // straight-line on purpose: a branch per value ("any candidate in the wave?") keeps the compiler from overlapping the sixteen
+                // values' LDS reads and chains, and the wave sat out each one in turn (round 3: 0.12 ms of a 1080p batch's 0.69)
+                const unsigned slot = st_nstaged + wave_rank_of(mk), sel = (cnd && slot < (unsigned)(TFFT_STAT_SLOTS - 1)) ? 0xFFFFFFFFu : 0u;
+                st_wbuf[(slot & sel) | ((unsigned)(TFFT_STAT_SLOTS - 1) & ~sel)] = rel | 0x80000000u;      // lanes without a candidate (or without room) write the spare slot
+                st_nstaged += (unsigned)__popcll(mk);       // beyond the slots: the tile is staged again below, value by value
+            }
+            // capacity (S:998-1008): bins of the annulus at or above the threshold window are counted; a value inside the window only
+            // leaves a mark (bit E-1-m of st_ambflag: rare, picked up from the parked tile below)
+            if (TFFT_STAT_CUT & 64) return;
+            const unsigned d1 = __umul24(row, row) + st_col2;           // rows < 2^13
+            const float x = (d1 - P.st_slo <= st_aspan) ? m2 : -1.0f;
+            st_capcount += !(x < st_t2hi) ? 1u : 0u;
+            st_ambflag = st_ambflag + st_ambflag + ((__float_as_uint(x) - st_t2lo_b < st_t2win) ? 1u : 0u);
+        };
         if (FULL) {
             char* ob = out_bytes + (size_t)tile * (C * sizeof(float2));
             char* mb = m2_bytes + (size_t)tile * (C * sizeof(float));
@@ -1196,12 +1300,14 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                 float2 v = u[m];
                 if (TW) v = cmul(v, lds_wo[t + m * T]);
                 if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[t + m * T], awc));      // last forward step: the rank-1 term comes back
-                if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
+                if (MODE == COLS_STAT) {        // nothing is stored
+                    st_value(m, (TFFT_STAT_CUT & 16) ? u[m] : v);
+                } else if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
                     if (P.em_m2 == 1) *reinterpret_cast<float*>(mb + m * (stride_out >> 1) + (vo >> 1)) = fmaf(v.x, v.x, v.y * v.y);      // asked for, nothing at all)
                 } else *reinterpret_cast<float2*>(ob + m * stride_out + vo) = v;
             }
-        } else if ((col < P.M) && (g < P.G)) {
-            float2* dst = out + plane_off;
+        } else if (((tile * ts + toff) * C + c < P.M) && (g < P.G)) {      // (the sample pass: input column tile*ts+toff, output column block tile of a narrow plane)
+            float2* dst = reinterpret_cast<float2*>(out_bytes);
             float* dst_m2 = reinterpret_cast<float*>(out + (size_t)img * P.img_stride) + (size_t)plane * P.plane_stride;
             const int to = (int)opaque_u32((unsigned)t);
 #pragma unroll
@@ -1214,11 +1320,11 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                     if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[k], awc));
                     if (MODE == COLS_EMIT && P.em_m2) {
                         if (P.em_m2 == 1) dst_m2[(unsigned)(row * P.M + col)] = fmaf(v.x, v.x, v.y * v.y);
-                    } else dst[(unsigned)(row * P.M + col)] = v;
+                    } else dst[(unsigned)(row * oM + col)] = v;
                 }
             }
         }
-        if (MODE == COLS_EMIT && P.em_m2 == 1 && tile == 0 && c == 0 && g < P.G) {      // the packed column 0 (its two real spectra cannot be told
+        if (((MODE == COLS_EMIT && P.em_m2 == 1) || MODE == COLS_STAT) && tile == 0 && c == 0 && g < P.G) {      // the packed column 0 (its two real spectra cannot be told
             float2* col0 = P.st_col0 + ((size_t)img * 3 + plane) * P.PH;                  // apart from magnitudes) travels beside the |F|^2 plane
             const int to = (int)opaque_u32((unsigned)t);
 #pragma unroll
@@ -1227,7 +1333,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                 if (row < out_rows) col0[(unsigned)row] = (DC && SIGN > 0) ? cadd(u[m], cmul(lds_ah[to + m * T], awc)) : u[m];
             }
         }
-        if (MODE == COLS_EMIT) {
+        if (MODE == COLS_EMIT || MODE == COLS_STAT) {
             // park the tile (as COLS_READ does) and write the values of the listed bins, DC term included, into the list the first
             // inverse step embeds from: em_fl[entry index], coalesced
             lds_barrier();            // the last gather of fft_block has been consumed by every thread
@@ -1235,6 +1341,55 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
             for (int m = 0; m < E; m++) lds[lay.idx(t + m * T, c)] = u[m];
             if (DC && t == 0) lds_aw[c] = awc;
             lds_barrier();
+            if (MODE == COLS_STAT) {
+                {
+                    auto st_again = [&](int m, float& m2, unsigned& row) -> bool {      // value m of this thread once more, from the parked tile; in the annulus?
+                        const int k = t + m * T;
+                        float2 v = lds[lay.idx(k, c)];
+                        if (DC) v = cadd(v, cmul(lds_ah[k], awc));
+                        m2 = fmaf(v.x, v.x, v.y * v.y);
+                        row = st_row0 + (unsigned)m * st_rstep;
+                        return row * row + st_col2 - P.st_slo <= st_aspan;
+                    };
+                    // rows 0 and PH/2 are axes, outside the count (S:698-700): st_value did not test for them -- the few lanes that hold
+                    // such a row take back what it counted there
+                    auto st_uncount = [&](int m) {
+                        float m2; unsigned row;
+                        if (st_again(m, m2, row) && !(m2 < st_t2hi)) st_capcount -= 1u;
+                    };
+                    const unsigned half = (unsigned)P.PH >> 1, dh = half - st_row0;
+                    if (st_valid && st_row0 == 0) st_uncount(0);
+                    if (st_valid && half != 0 && half >= st_row0 && dh % st_rstep == 0 && dh / st_rstep < (unsigned)E) st_uncount((int)(dh / st_rstep));
+                    // the staged candidates leave once per tile (a wave stages ~50 of its 1024 values; 192 fit).  A tile with more -- a
+                    // bracket gone wide, a flat image -- is staged again from the parked values, flushing as it goes
+                    if (st_nstaged > (unsigned)(TFFT_STAT_SLOTS - 1)) {
+                        st_nstaged = 0;
+                        for (int m = 0; m < E; m++) {
+                            float m2; unsigned row;
+                            (void)st_again(m, m2, row);
+                            const unsigned rel = __float_as_uint(st_valid ? m2 : -1.0f) - st_base;
+                            const bool cnd = rel <= st_span_b;
+                            const unsigned long long mk = __ballot(cnd);
+                            if (cnd) st_wbuf[st_nstaged + wave_rank_of(mk)] = rel | 0x80000000u;
+                            st_nstaged += (unsigned)__popcll(mk);
+                            if (st_nstaged > 64) st_flush();
+                        }
+                    }
+                    if (st_nstaged) st_flush();
+                    // values inside the threshold window: kept for k_capacity_settle, which knows the median
+                    if (__ballot(st_ambflag != 0)) {
+                        for (int m = 0; m < E; m++) {
+                            if (!((st_ambflag >> (E - 1 - m)) & 1u)) continue;
+                            float m2; unsigned row;
+                            if (st_again(m, m2, row) && !(m2 < st_t2lo) && m2 < st_t2hi && row != 0 && 2u * row != (unsigned)P.PH) {
+                                const unsigned slot = atomicAdd(&st_s->n_amb, 1u);
+                                if (slot < TFFT_AMB_CAP) st_ambo[slot] = m2;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!PF && MODE == COLS_STAT) em_entries(tile, enC, false);
             {
                 unsigned e0, e1;
                 em_range(tile, e0, e1);
@@ -1264,6 +1419,20 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
             awc = awn;
+        }
+    }
+    if (MODE == COLS_STAT) {            // the workgroup's sums: one global atomic each (a per-thread atomic on one address per plane serialises)
+        st_fill();
+        lds_barrier();
+        if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) { st_wcnt[0] = 0; st_wcnt[1] = 0; }
+        lds_barrier();
+        if (st_below) atomicAdd(&st_wcnt[0], 2u * st_below);          // a stored bin = two full-grid bins of equal magnitude
+        if (st_capcount) atomicAdd(&st_wcnt[1], st_capcount);       // corrections may be negative: the sums wrap back
+        lds_barrier();
+        if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+            if (st_wcnt[0]) atomicAdd(&st_s->below, (unsigned long long)st_wcnt[0]);
+            if (P.st_cap && st_wcnt[1])
+                atomicAdd(&P.st_partial[((size_t)img * 3 + plane) * TFFT_STAT_MAX_BLOCKS + ((blockIdx.y * gridDim.x + blockIdx.x) % TFFT_STAT_MAX_BLOCKS)], st_wcnt[1]);
         }
     }
 }
@@ -1637,7 +1806,7 @@ __device__ __forceinline__ unsigned long long stage_hist(const SelectState* s, u
 __global__ void k_select_init(SelectState* __restrict__ st, unsigned long long rank) {
     SelectState* s = st + blockIdx.x;
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) s->hist[i] = 0;
-    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->lo = 0; s->hi = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f; }
+    if (threadIdx.x == 0) { s->rank = rank; s->prefix = 0; s->n_cand = 0; s->cand_fixed = 0; s->done = 0; s->below = 0; s->lo = 0; s->hi = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f; }
 }
 
 // ---- fast path ----------------------------------------------------------------------------------
@@ -1658,7 +1827,7 @@ __global__ void k_select_guess(SelectState* __restrict__ st, double magmin, unsi
     if (threadIdx.x == 0) {
         const unsigned lo = (unsigned)(b > 0 ? b - 1 : 0), hi = (unsigned)(b < 4095 ? b + 1 : 4095);
         s->lo = lo; s->hi = hi;
-        s->rank = rank; s->prefix = 0; s->n_cand = 0; s->done = 0; s->below = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f;
+        s->rank = rank; s->prefix = 0; s->n_cand = 0; s->cand_fixed = 0; s->done = 0; s->below = 0; s->fast = 0; s->n_amb = 0; s->t2_lo = 0.f; s->t2_hi = 0.f;
         if (magmin >= 0.0) {
             // the median's |F|^2 lies in [bits(lo<<19), bits((hi+1)<<19)); sqrtf and mag2_threshold are monotone, so the capacity
             // threshold T2 = mag2_threshold(magmin * sqrtf(.)) lies in [t2_lo, t2_hi]
@@ -1945,7 +2114,7 @@ __global__ void k_select_fast(SelectState* __restrict__ st, float* __restrict__ 
             else { med_out[blockIdx.x] = sqrtf(__uint_as_float((s->lo << 19) + (s->prefix << 11) + (unsigned)b)); s->done = 1; s->fast = 1; }
         }
     } else if (threadIdx.x == 0) {
-        s->n_cand = 0; s->prefix = 0; s->done = 0;      // s->rank is untouched: the fallback starts from it
+        s->n_cand = 0; s->cand_fixed = 0; s->prefix = 0; s->done = 0;      // s->rank is untouched: the fallback starts from it
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256) s->hist[i] = 0;
@@ -1961,10 +2130,11 @@ __global__ void k_hist_cand(SelectState* __restrict__ st, const unsigned* __rest
     unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);
     for (int i = threadIdx.x; i < NB; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    const unsigned want = FAST ? s->prefix : (s->prefix & 1023u), n = s->n_cand;
+    const unsigned want = FAST ? s->prefix : (s->prefix & 1023u), n = s->cand_fixed + s->n_cand;
     const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned c = in[i], v = c & 0x7FFFFFFFu;
+        if (c == TFFT_CAND_HOLE) continue;
         if (FAST) { if ((v >> 11) == want) atomicAdd(&hist[v & 2047u], (c >> 31) ? 2u : 1u); }
         else { if (((v >> 9) & 1023u) == want) atomicAdd(&hist[v & 511u], (c >> 31) ? 2u : 1u); }
     }
@@ -1993,13 +2163,31 @@ __global__ void k_col0_stats(const float2* __restrict__ col0, int PH, SelectStat
             if (bk < lo) below++;
             else if (bk - lo <= span) {
                 const unsigned rel = v[i] - base_bits;
-                out[atomicAdd(&s->n_cand, 1u)] = rel;                                           // weight 1: bit 31 clear
+                out[s->cand_fixed + atomicAdd(&s->n_cand, 1u)] = rel;                           // weight 1: bit 31 clear
                 if (with_hist) atomicAdd(&s->hist[rel >> 11], 1u);                              // the level-2 histogram k_collect_bracket keeps
             }
         }
     }
     if (below) atomicAdd(&s->below, (unsigned long long)below);
 }
+// (b) the level-2 histogram of the candidates (k_collect_bracket builds it while it stages them)
+__global__ void k_hist_cand2(SelectState* __restrict__ st, const unsigned* __restrict__ cand, size_t cand_stride) {
+    SelectState* s = sel_of(st);
+    unsigned* hist = reinterpret_cast<unsigned*>(tfft_smem);
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const unsigned n = s->cand_fixed + s->n_cand;
+    const unsigned* in = cand + ((size_t)blockIdx.z * 3 + blockIdx.y) * cand_stride;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned c = in[i], v = c & 0x7FFFFFFFu;
+        if (c == TFFT_CAND_HOLE) continue;
+        atomicAdd(&hist[(v >> 11) & 1023u], (c >> 31) ? 2u : 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+        if (hist[i]) atomicAdd(&s->hist[i], hist[i]);
+}
+
 // ---- compact pipeline (planes up to 2^24 bins): the three launches after the bracket pass in one, the six fallback launches
 // in one.  A single image spends its time in the GPU-side latency of dependent launches (~6.7 us each: the statistics were 16 of
 // the ~35 of a 1080p round trip), not in the kernels.
@@ -2039,7 +2227,7 @@ __global__ void __launch_bounds__(1024) k_select_finish(SelectState* __restrict_
     const bool ok = !(rank < below || rank - below >= total);       // verifies the bracket: exact result or declared failure
     for (int i = t; i < 4096; i += blockDim.x) s->hist[i] = 0;        // leave the global histogram clean for whoever comes next
     if (!ok) {
-        if (t == 0) { s->n_cand = 0; s->prefix = 0; s->done = 0; }  // k_median_fallback takes over
+        if (t == 0) { s->n_cand = 0; s->cand_fixed = 0; s->prefix = 0; s->done = 0; }  // k_median_fallback takes over
         return;
     }
     int b2; unsigned long long before;
@@ -2047,11 +2235,11 @@ __global__ void __launch_bounds__(1024) k_select_finish(SelectState* __restrict_
     const unsigned long long rank3 = rank - below - before;
     for (int i = t; i < 4096; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    const unsigned n = s->n_cand;
+    const unsigned n = s->cand_fixed + s->n_cand;
     const unsigned* in = cand + (size_t)blockIdx.x * cand_stride;
     for (unsigned i = t; i < n; i += blockDim.x) {
         const unsigned c = in[i], v = c & 0x7FFFFFFFu;
-        if ((v >> 11) == (unsigned)b2) atomicAdd(&h[v & 2047u], (c >> 31) ? 2u : 1u);
+        if (c != TFFT_CAND_HOLE && (v >> 11) == (unsigned)b2) atomicAdd(&h[v & 2047u], (c >> 31) ? 2u : 1u);
     }
     int b3;
     find_bucket_blk(h, p1, p2, res, rank3, 2048, b3, before);
@@ -2534,24 +2722,33 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    if constexpr (!FULL && LOGL >= 6 && MODE != COLS_ROWLIMIT) {
+    if constexpr (!FULL && (LOGL >= 6 || MODE == COLS_STAT) && MODE != COLS_ROWLIMIT) {
         // every output element exists: the variant whose stores carry no predicate (ROWLIMIT cuts rows by definition)
         const int rows_out_max = P.out_a * (L - 1) + P.out_b * (P.G - 1);
         if (rows_out_max < P.out_rows && P.M % C == 0 && P.G % gpb == 0)
             return launch_cols_t<LOGL, SIGN, MODE, DC, TW, true>(in, out, tw, P, n_planes, s);
+        if (MODE == COLS_STAT) return hipErrorInvalidValue;      // the in-register classification lives in the unpredicated store loop only
     }
     const size_t lds0 = (size_t)gpb * L * C * sizeof(float2) + (DC ? (size_t)gpb * L * sizeof(float2) : 0) + (TW ? (size_t)gpb * L * sizeof(float2) : 0) +
                        (LOGL >= TFFT_COLS_LDS_TW_LOG ? (size_t)L * sizeof(float2) : 0);
-    const int ntiles = (P.M + C - 1) / C;
+    int ntiles = (P.M + C - 1) / C;
+    if (MODE == COLS_PLAIN && SIGN > 0 && P.tile_step > 1) ntiles = (ntiles - P.tile_off + P.tile_step - 1) / P.tile_step;      // the statistics' sample: every tile_step-th tile
     int tpb = P.tiles_per_block > 0 ? P.tiles_per_block : 1;
     ColParams Q = P;
-    constexpr bool BUCKETS = (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT);
+    constexpr bool BUCKETS = (MODE == COLS_READ || MODE == COLS_EMBED || MODE == COLS_EMIT || MODE == COLS_STAT);
     if (BUCKETS) {          // the bucket offsets of a workgroup's tiles are staged in LDS: 16 tiles + sentinel per group
         if (tpb > 16) tpb = 16;
         Q.tiles_per_block = tpb;
     }
-    const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0);
+    const size_t nwaves = ((size_t)C * T * gpb + 63) / 64;
+    const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
+                       (MODE == COLS_STAT ? (nwaves * (TFFT_STAT_SLOTS + 1) + 2) * sizeof(unsigned) : 0);
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
+    if (MODE == COLS_STAT) {
+        const size_t fixed = (size_t)grid.x * grid.y * nwaves * TFFT_STAT_RESV;
+        if (fixed + (size_t)P.PH * (P.M + 1) > P.st_cand_stride) return hipErrorInvalidValue;
+        Q.st_cand_fixed = (unsigned)fixed;
+    }
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW, FULL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2567,7 +2764,9 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
     if (P.em_on && (!P.rd_bins || (sign < 0 && P.dc_ah) || (sign > 0 && P.last_row_dev))) return hipErrorInvalidValue;      // delta embedding: EMIT (forward, final step) / EMBED (inverse, first step, DC term absent)
     if (P.tw_out && sign > 0 && (P.dc_ah || P.rd_bins || P.last_row_dev)) return hipErrorInvalidValue;      // forward variants belong to the final step (no output twiddle)
     if (P.em_on && !P.em_fl) return hipErrorInvalidValue;
-    if (P.rd_bins && !P.trash) return hipErrorInvalidValue;       // the bucket modes redirect the stores of idle lanes to the context's scratch line
+    if (P.rd_bins && !P.trash) return hipErrorInvalidValue;
+    if (P.st_sel && (!P.em_on || sign < 0 || logl > 9 || logl < 4 || !P.st_cand || !P.st_col0 || (P.st_cap && (!P.st_partial || !P.st_amb)))) return hipErrorInvalidValue;
+    if ((P.tile_step > 1 || P.gate) && (sign < 0 || P.rd_bins || P.last_row_dev || P.tw_out)) return hipErrorInvalidValue;      // plain final forward step only       // the bucket modes redirect the stores of idle lanes to the context's scratch line
     if (P.em_m2 && sign > 0 && (!P.em_on || !P.st_col0)) return hipErrorInvalidValue;      // (the inverse step ignores it)
 #define G(n, MODE)                                                                      \
     (P.dc_ah ? launch_cols_t<(n <= 9 ? n : 9), +1, MODE, true>(in, out, tw_ph, P, n_planes, s) \
@@ -2581,7 +2780,7 @@ hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const
 #define F(n)                                                                            \
     return sign < 0 ? (P.em_on ? GE(n) : P.dc_ah ? GI(n, true) : GI(n, false)) \
          : P.tw_out ? launch_cols_t<(n <= 9 ? n : 9), +1, COLS_PLAIN, false, true>(in, out, tw_ph, P, n_planes, s) \
-         : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
+         : (P.em_on && P.st_sel) ? G(n, COLS_STAT) : P.em_on ? G(n, COLS_EMIT) : P.rd_bins ? G(n, COLS_READ) : P.last_row_dev ? G(n, COLS_ROWLIMIT) : G(n, COLS_PLAIN)
     TFFT_DISPATCH_LOG(logl, F)
 #undef F
 #undef G
@@ -2745,6 +2944,54 @@ hipError_t launch_medians(const float2* spec, int PH, int PW, size_t img_stride,
             hipError_t e = launch_capacity(spec, *cap, n_images, med_out, partial, usable, s, flag);
             if (e != hipSuccess) return e;
         }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_skew_bracket(SelectState* st, int n_images, int skew, hipStream_t s) {
+    hipLaunchKernelGGL(k_skew_bracket, dim3(3 * n_images), dim3(64), 0, s, st, skew);
+    return hipGetLastError();
+}
+// ---- statistics inside the last forward column step (COLS_STAT): the launches around it.
+// (1) bracket guess from a sample of the column tiles (a narrow spectrum of Ms columns written by the plain step with tile_step)
+hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t mini_img_stride, int n_images, SelectState* st, const CapParams* cap,
+                             unsigned* partial, int col0_packed, hipStream_t s) {
+    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
+    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    hipError_t e = hipMemsetAsync(partial, 0, (size_t)n_images * (3 * TFFT_STAT_MAX_BLOCKS + 1) * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    int step = (int)(((long long)PH * Ms) / 65536); if (step < 1) step = 1; if (step > 64) step = 64;       // ~65 k sampled values per plane
+    unsigned nbs = (unsigned)((PH + step - 1) / step);
+    { unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < 32u ? want : 32u; }
+    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed, (const float2*)nullptr);
+    hipLaunchKernelGGL(k_select_guess, dim3(3 * n_images), dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
+    return hipGetLastError();
+}
+// (2) after the COLS_STAT step: the packed column 0, the candidates' level-2 histogram, the verified select
+hipError_t launch_stat_select(int PH, int n_images, SelectState* st, unsigned* cand, size_t cand_stride, float* med_out, const float2* col0, hipStream_t s) {
+    const unsigned sel_lds = (4096 + 256 + 16 + 4) * sizeof(unsigned);
+    const dim3 gs(3 * n_images);
+    hipLaunchKernelGGL(k_col0_stats, dim3((PH + 255) / 256, 3, n_images), dim3(256), 0, s, col0, PH, st, cand, cand_stride, 0);
+    unsigned nbh = (unsigned)((1024 + 3 * n_images - 1) / (3 * n_images));
+    if (nbh < 16) nbh = 16;
+    if (nbh > 256) nbh = 256;
+    hipLaunchKernelGGL(k_hist_cand2, dim3(nbh, 3, n_images), dim3(256), 1024 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select_fast<2>, gs, dim3(256), sel_lds, s, st, med_out);
+    hipLaunchKernelGGL(k_hist_cand<true>, dim3(nbh, 3, n_images), dim3(256), 2048 * sizeof(unsigned), s, st, cand, cand_stride);
+    hipLaunchKernelGGL(k_select_fast<3>, gs, dim3(256), sel_lds, s, st, med_out);
+    return hipGetLastError();
+}
+// (3) the planes the fast path could not settle (their spectrum has been produced by the gated plain step in between), the capacity
+hipError_t launch_stat_settle(const float2* spec, int PH, int PW, size_t img_stride, int n_images, SelectState* st, float* med_out, const CapParams* cap,
+                              unsigned* partial, float* amb, unsigned long long* usable, hipStream_t s) {
+    const int M = PW >> 1;
+    const unsigned long long rank = ((unsigned long long)PH * PW) / 2;
+    const unsigned fin_lds = (4096 + 256 + 16) * sizeof(unsigned) + 4 * sizeof(unsigned long long);
+    hipLaunchKernelGGL(k_median_fallback, dim3(3 * n_images), dim3(1024), fin_lds, s, spec, PH, M, img_stride, st, med_out, rank, 0, (const float2*)nullptr);
+    if (cap) {
+        unsigned* flag = partial + (size_t)n_images * 3 * TFFT_STAT_MAX_BLOCKS;
+        hipLaunchKernelGGL(k_capacity_settle, dim3(n_images), dim3(192), 64, s, st, med_out, cap->magmin, partial, (int)TFFT_STAT_MAX_BLOCKS, amb, usable, flag,
+                           spec, *cap, 1, 0);
     }
     return hipGetLastError();
 }

@@ -45,6 +45,17 @@ unsigned long long emu_ballot(int pred) {
     return r;
 }
 
+// the value lane 0 of the wave holds (every lane of the wave calls)
+namespace { unsigned rfl_acc[16]; }
+unsigned emu_readfirstlane(unsigned v) {
+    const unsigned w = linear_tid() >> 6, l = linear_tid() & 63u;
+    if (l == 0) rfl_acc[w] = v;
+    emu_wave_sync();
+    const unsigned r = rfl_acc[w];
+    emu_wave_sync();
+    return r;
+}
+
 void emu_launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     if (shmem > sizeof(tfft::tfft_smem)) { fprintf(stderr, "emu: %zu bytes of LDS requested\n", shmem); abort(); }
     const size_t nt = (size_t)block.x * block.y * block.z;

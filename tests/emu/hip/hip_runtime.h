@@ -58,8 +58,11 @@ void emu_wave_sync();
 // wave collectives (call sites must be wave uniform, as on the hardware path they are used in)
 unsigned long long emu_ballot(int pred);
 unsigned emu_lane();
+unsigned emu_readfirstlane(unsigned v);
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane((unsigned)(v))
 #define __ballot(p) emu_ballot((p) ? 1 : 0)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline unsigned emu_mbcnt_lo(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (unsigned)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
 static inline unsigned emu_mbcnt_hi(unsigned m, unsigned init) { const unsigned l = emu_lane(); return init + (l < 32 ? 0u : (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u))); }
 static inline unsigned emu_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3))); }

@@ -671,7 +671,10 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     # TFFT_STATS_SKEW (test hook): every bracket moved off the median -- the fast path of the statistics fails and their fallbacks
     # (on the |F|^2 planes the delta pipeline stores) must return the same capacities
     # ... TFFT_STATS_M2=0 / TFFT_STATS_ASYNC=0: the statistics on the complex spectrum, in line (the A/B forms of the default)
-    for env in ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}):
+    # ... TFFT_STATS_TILE=0: the |F|^2 planes + the statistics kernels over them instead of the classification inside the last forward
+    # column step (the default since round 3); with the skew the gated fallback of either form runs
+    for env in ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_SKEW": "5"},
+                {"TFFT_STATS_TILE": "0", "TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}):
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
             ctx.set_bit_index(idx)
@@ -709,12 +712,14 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     return stats
 
 
-def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0))):
+def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0)), flat=False):
     """Capacity counted inside the medians' full pass (batch path, S:998-1008) == tfft_capacity with thr = magmin * median,
     image by image, exactly: default annulus, an annulus that reaches into the mirror half (rmax > 0.5), thresholds at and
     above the median (thousands of bins inside the threshold's bracket: the parked list overflows and the plain kernel
     recounts), magmin = 0, and the forced median fallback."""
     imgs = np.stack([cover_rgb(w, h, 70 + i) for i in range(nimg)])
+    if flat:      # a flat image: every bin but a few has the same magnitude -- all of them land in the median's bracket (the in-kernel
+        imgs[0][:] = 77      # statistics stage a tile's candidates in 192 LDS slots per wave: here every tile overflows them)
     ph, pw = 1 << (h - 1).bit_length(), 1 << (w - 1).bit_length()
     bins = B.Walk(bytes(range(32)), ph, pw, 0.0, 1.5, 0.9, lib=lib).next(16)
     bits = np.ones((nimg, 16), np.uint8)
