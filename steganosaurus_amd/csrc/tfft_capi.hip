@@ -55,8 +55,6 @@ struct tfft_ctx {
     float2* spec_pool = nullptr;
     float2* tmp_pool = nullptr;
     unsigned* cand_pool = nullptr;
-    float2* mini_pool = nullptr;          // [n_slots*3*max_ph*mini_cols] the sample of column tiles the tile statistics guess their bracket from
-    size_t mini_cols = 0;
     int stats_tile = 1;                   // batched delta embeds run the statistics' bracket pass inside the last forward column step and never store
                                           // the spectrum or |F|^2 (TFFT_STATS_TILE=0: |F|^2 planes + the statistics kernels over them, round 2's default)
     int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
@@ -114,6 +112,7 @@ struct tfft_ctx {
     int cols_tiles_forced = 0;            // TFFT_COLS_TILES given: it also rules the COLS_EMIT step (default there: 2 tiles per workgroup up to L = 256, r3h A/B: 0.601 vs 0.630 ms per 32 x 1080p launch)
     int cols_tiles_embed = 0;             // delta embedding: tiles per workgroup of the first inverse step; 0 = 8 for columns up to 256, 2 from 512 on
                                           // (round 3 A/B, gpurun_out/r3h, per 32 x 1080p launch: 0.490 / 0.437 / 0.404 / 0.394 ms with 2 / 4 / 8 / 16; per 8 x 4K: 0.563 / 0.501 / 0.511 / 0.518 with 1 / 2 / 4 / 8)
+    int cols_tiles_stat = 16;             // COLS_STAT: tiles per workgroup (nothing is stored: as the tile-resident read; r4d A/B 1080p x 32: 2.048 / 2.024 / 2.000 / 1.997 ms per embed with 2 / 4 / 8 / 16)
     int cols_tiles_read = 16;             // the tile-resident read walks longer runs (A/B: 0.422 vs 0.455 ms per 32x1080p launch; the storing steps prefer 8)
     int median_force_fallback = 0;
 #ifndef TFFT_NO_GRAPHS
@@ -220,8 +219,9 @@ static void copy_embed_fields(ColParams& cp, const ColParams& e) {
 }
 
 static void copy_plain_extra(ColParams& cp, const ColParams& e) {
-    if (e.tile_step > 1) cp.tiles_per_block = 1;      // the sample: an eighth of the tiles, one per workgroup keeps the grid wide
+    if (e.tile_step > 1) cp.tiles_per_block = e.hist_sel ? 2 : 1;      // the sample: an eighth of the tiles; few per workgroup keep the grid wide
     cp.tile_step = e.tile_step; cp.tile_off = e.tile_off; cp.out_M = e.out_M; cp.out_plane_stride = e.out_plane_stride; cp.out_img_stride = e.out_img_stride; cp.gate = e.gate;
+    cp.hist_sel = e.hist_sel;
 }
 
 // How a launch sequence wants the outer column steps and the inverse row kernel to run: handed down explicitly per call (until round 3
@@ -234,6 +234,8 @@ struct StageMode {
     const uint8_t* inv_cover = nullptr;    // ... and the inverse row kernel adds its transform to these cover pixels
     const ColParams* fwd_plain_extra = nullptr;   // plain last forward step: tile_step / out_* (the statistics' sample) or gate fields, and ...
     float2* fwd_out_override = nullptr;           // ... its output buffer
+    bool inv_via_spec = false;             // delta embedding: the inverse keeps its intermediate in `spec` (nothing reads F there), so `tmp` -- the
+                                           // input of the last forward step -- survives for the gated fallback of the in-kernel statistics
 };
 
 int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_in, uint8_t* rgb_out, hipStream_t st, const StageMode& md = StageMode()) {
@@ -267,7 +269,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
                 if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
-                else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
+                else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; if (cp.st_sel && c->cols_tiles_stat) cp.tiles_per_block = c->cols_tiles_stat; }
                 else if (md.fwd_plain_extra) copy_plain_extra(cp, *md.fwd_plain_extra);
                 HIPCHK(c, launch_cols(tmp, md.fwd_out_override ? md.fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             } else {   // for every n2: length-N1 FFT over rows n1*N2+n2, times w^(n2*k1), in place
@@ -285,7 +287,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                 rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
             }
             if (md.fwd_read) { const ColParams& r = *md.fwd_read; cp.rd_bins = r.rd_bins; cp.rd_off = r.rd_off; cp.rd_bits = r.rd_bits; cp.rd_n = r.rd_n; cp.trash = c->trash; cp.tiles_per_block = c->cols_tiles_read; }
-            else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; }
+            else if (md.fwd_emit) { copy_embed_fields(cp, *md.fwd_emit); if (!c->cols_tiles_forced && pl.log_n2 <= 8) cp.tiles_per_block = 2; if (cp.st_sel && c->cols_tiles_stat) cp.tiles_per_block = c->cols_tiles_stat; }
                 else if (md.fwd_plain_extra) copy_plain_extra(cp, *md.fwd_plain_extra);
             HIPCHK(c, launch_cols(tmp, md.fwd_out_override ? md.fwd_out_override : spec, tw_h, cp, pl.log_n2, +1, 3 * n, st));
             return TFFT_OK;
@@ -297,7 +299,7 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
                 }
-                HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
+                HIPCHK(c, launch_cols(spec, md.inv_via_spec ? spec : tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             } else {   // for every k1: length-N2 inverse over rows k1+N1*k2 -> rows k1*N2+n2, times w^-(n2*k1)
                 cp.G = N1; cp.in_a = N1; cp.in_b = 1; cp.out_a = 1; cp.out_b = N2; cp.in_rows = s.PH; cp.out_rows = s.PH; cp.tw_out = 1;
                 if (md.inv_embed) { copy_embed_fields(cp, *md.inv_embed); cp.tiles_per_block = c->cols_tiles_embed ? c->cols_tiles_embed : (pl.log_n2 >= 9 ? 2 : 16); }
@@ -305,20 +307,21 @@ int enqueue_fft_stage(tfft_ctx* c, int s0, int n, int stage, const uint8_t* rgb_
                     rc = get_dc_table(c, s.H, s.PH, s.center, 0, (double)c->dc_bias, &cp.dc_ah); if (rc) return rc;
                     rc = get_dc_table(c, s.W, s.PWi, s.center, 1, 1.0, &cp.dc_aw); if (rc) return rc;
                 }
-                HIPCHK(c, launch_cols(spec, tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
+                HIPCHK(c, launch_cols(spec, md.inv_via_spec ? spec : tmp, tw_h, cp, pl.log_n2, -1, 3 * n, st));
             }
             return TFFT_OK;
         case COLS_INV_B:
             if (pl.direct || pl.fused_fwd) return TFFT_OK;      // fused: done inside ROWS_INV
             // for every n2: length-N1 inverse over rows k1*N2+n2 -> rows n1*N2+n2 (< H only), in place
             cp.G = N2; cp.in_a = N2; cp.in_b = 1; cp.out_a = N2; cp.out_b = 1; cp.in_rows = s.PH; cp.out_rows = s.H; cp.tw_out = 0;
-            HIPCHK(c, launch_cols(tmp, tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
+            HIPCHK(c, launch_cols(md.inv_via_spec ? spec : tmp, md.inv_via_spec ? spec : tmp, tw_h, cp, pl.log_n1, -1, 3 * n, st));
             return TFFT_OK;
         case ROWS_INV: {
             RowParams rp{s.W, s.H, s.PWi, s.PH, s.center, (float)(1.0 / ((double)M * (double)s.PH)), c->slot_stride, c->dc_bias, nullptr};
             if (md.inv_cover) { rp.cover = md.inv_cover; rp.bias = 0.f; }      // delta embedding: the transform of F' - F has no DC term to give back
-            if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
-            else HIPCHK(c, launch_rows_inv(tmp, rgb_out, tw_w, rp, n, st));
+            if (md.inv_via_spec && !md.inv_embed) return TFFT_E_INVALID;      // only the delta inverse reads nothing from `spec`
+            if (pl.fused_fwd) HIPCHK(c, launch_colrow_inv(md.inv_via_spec ? spec : tmp, rgb_out, tw_w, rp, n, st));       // column step B' + rows
+            else HIPCHK(c, launch_rows_inv(md.inv_via_spec ? spec : tmp, rgb_out, tw_w, rp, n, st));
             return TFFT_OK;
         }
         default: return TFFT_E_INVALID;
@@ -570,6 +573,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("TFFT_COLS_TILES_STAT")) c->cols_tiles_stat = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_READ")) c->cols_tiles_read = atoi(e) > 0 ? atoi(e) : 1;
     if (c->cols_direct_max_log > 10) c->cols_direct_max_log = 10;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TFFT_E_HIP; }
@@ -587,7 +591,6 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (!rc) rc = dev_alloc(c, (void**)&c->spec_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->tmp_pool, ns * c->slot_stride * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->cand_pool, ns * 3 * c->cand_stride * sizeof(unsigned));
-    c->mini_cols = (size_t)(next_pow2(max_w) < 2 ? 1 : next_pow2(max_w) / 2) / 8 + 16;          // (mini_pool itself is allocated by the first call that uses the tile statistics)
     if (!rc) rc = dev_alloc(c, (void**)&c->col0_pool, ns * 3 * (size_t)ph * sizeof(float2));
     if (!rc) rc = dev_alloc(c, (void**)&c->sel, ns * 3 * sizeof(SelectState));
     if (!rc) rc = dev_alloc(c, (void**)&c->med, ns * 3 * sizeof(float));
@@ -611,7 +614,7 @@ int tfft_destroy(tfft_ctx* c) {
     (void)hipDeviceSynchronize();
     invalidate_graphs(c);
     (void)hipFree(c->img_pool); (void)hipFree(c->spec_pool); (void)hipFree(c->tmp_pool); (void)hipFree(c->cand_pool);
-    (void)hipFree(c->mini_pool); (void)hipFree(c->col0_pool);
+    (void)hipFree(c->col0_pool);
     (void)hipFree(c->sel); (void)hipFree(c->med); (void)hipFree(c->partial); (void)hipFree(c->amb); (void)hipFree(c->usable); (void)hipFree(c->err); (void)hipFree(c->ex_cand); (void)hipFree(c->ex_val); (void)hipFree(c->ex_below); (void)hipFree(c->ex_n); for (auto& kv : c->ex_table) (void)hipFree(kv.second); (void)hipFree(c->trash); (void)hipFree(c->bit_index); (void)hipFree(c->last_row);
     for (auto& b : c->tb) { (void)hipFree(b.cnt); (void)hipFree(b.off); (void)hipFree(b.ent); (void)hipFree(b.fl); (void)hipFree(b.pb); }
     for (auto& kv : c->tw) (void)hipFree(kv.second);
@@ -1069,10 +1072,35 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
 // forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
+// The statistics after COLS_STAT, in two parts so that the first can run beside the inverse transform (embed_chunk):
+//   select: the medians out of the staged candidates (5 small dependent launches, ~75 us of latency for a 32 x 1080p launch)
+//   tail  : images with a plane the fast path could not settle get their spectrum after all -- the plain last forward step, gated (it
+//           returns at once for the others) -- then the fallback kernels and the capacities.  Reads `tmp` (the last step's input):
+//           the inverse in between keeps its intermediate in `spec` (StageMode::inv_via_spec)
+static int enqueue_tilestats_select(tfft_ctx* c, int s0, int g, hipStream_t st) {
+    const Slot& s = c->slots[s0];
+    HIPCHK(c, launch_stat_select(s.PH, g, c->sel + 3 * s0, c->cand_pool + (size_t)3 * s0 * c->cand_stride, c->cand_stride, c->med + 3 * s0,
+                                 c->col0_pool + (size_t)s0 * 3 * s.PH, st));
+    return TFFT_OK;
+}
+static int enqueue_tilestats_tail(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, hipStream_t st, const CapParams& cap, unsigned long long* usable) {
+    const Slot& s = c->slots[s0];
+    const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
+    ColParams gt{};
+    gt.gate = c->sel + 3 * s0;
+    StageMode mg; mg.fwd_plain_extra = &gt;
+    int rc = enqueue_fft_stage(c, s0, g, pl.direct ? COLS_FWD_A : COLS_FWD_B, rgb_in, nullptr, st, mg);
+    if (rc) return rc;
+    HIPCHK(c, launch_stat_settle(c->spec(s0), s.PH, s.PWi, c->slot_stride, g, c->sel + 3 * s0, c->med + 3 * s0, &cap,
+                                 c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1), c->amb + (size_t)3 * s0 * TFFT_AMB_CAP, usable, st));
+    for (int i = 0; i < g; i++) { c->slots[s0 + i].has_spec = false; c->slots[s0 + i].rgb_src = nullptr; }
+    return TFFT_OK;
+}
+
 // phases (tfft_profile_stage times them apart): 1 the steps before the last column step, 2 sample + bracket guess, 4 the COLS_STAT step,
-// 8 select + gated spectrum + fallbacks + capacity
+// 8 select, 16 gated spectrum + fallbacks + capacity
 static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, hipStream_t st, ColParams& em, const CapParams& cap,
-                                     unsigned long long* usable, int phases = 15) {
+                                     unsigned long long* usable, int phases = 31) {
     const Slot& s = c->slots[s0];
     const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
     const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
@@ -1081,33 +1109,29 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     const int M = s.PWi / 2, ntiles = (M + 15) / 16, step = c->stats_tile_step;
     const int off = ntiles > step / 2 ? step / 2 : 0;
     const int Ms = 16 * ((ntiles - off + step - 1) / step);
-    if ((size_t)Ms > c->mini_cols) return TFFT_E_STATE;
-    if (!c->mini_pool) {
-        (void)hipStreamSynchronize(c->stream);
-        invalidate_graphs(c);
-        if (dev_alloc(c, (void**)&c->mini_pool, (size_t)c->n_slots * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols * sizeof(float2))) return TFFT_E_NOMEM;
-    }
     int rc;
     for (int stage : {ROWS_FWD, COLS_FWD_A}) {
         if (stage == final_fwd || !(phases & 1)) break;
         rc = enqueue_fft_stage(c, s0, g, stage, rgb_in, nullptr, st);
         if (rc) return rc;
     }
-    float2* mini = c->mini_pool + (size_t)s0 * 3 * (size_t)next_pow2(c->max_h) * c->mini_cols;
     float2* col0 = c->col0_pool + (size_t)s0 * 3 * s.PH;
     SelectState* sel = c->sel + 3 * s0;
     unsigned* partial = c->partial + (size_t)s0 * (3 * TFFT_STAT_MAX_BLOCKS + 1);
     float* amb = c->amb + (size_t)3 * s0 * TFFT_AMB_CAP;
     unsigned* cand = c->cand_pool + (size_t)3 * s0 * c->cand_stride;
-    // (1) every step-th column tile -> a narrow spectrum; its histogram brackets the medians
+    // (1) every step-th column tile, transformed and dropped into a histogram of |F|^2 (in LDS, ColParams::hist_sel): its median
+    // brackets the plane's.  (First form: the tiles written side by side as a narrow spectrum + k_hist_spec over it -- 0.15 ms of a
+    // 32 x 1080p launch where this takes 0.0x.)
     ColParams ex{};
     ex.tile_step = step; ex.tile_off = off; ex.out_M = Ms; ex.out_plane_stride = (size_t)s.PH * Ms; ex.out_img_stride = (size_t)3 * s.PH * Ms;
+    ex.hist_sel = sel;
     if (phases & 2) {
         StageMode ms;
-        ms.fwd_plain_extra = &ex; ms.fwd_out_override = mini;
+        ms.fwd_plain_extra = &ex;
         rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st, ms);
         if (rc) return rc;
-        HIPCHK(c, launch_stat_guess(mini, s.PH, s.PWi, Ms, ex.out_img_stride, g, sel, &cap, partial, off == 0 ? 1 : 0, st));
+        HIPCHK(c, launch_stat_guess(nullptr, s.PH, s.PWi, Ms, ex.out_img_stride, g, sel, &cap, partial, 0, st));
         if (c->stats_skew) HIPCHK(c, launch_skew_bracket(sel, g, c->stats_skew, st));
     }
     // (2) the last forward step: values of the listed bins + the bracket pass on every value
@@ -1120,16 +1144,11 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     em.st_sel = nullptr;
     if (rc) return rc;
     }
-    if (!(phases & 8)) return TFFT_OK;
-    HIPCHK(c, launch_stat_select(s.PH, g, sel, cand, c->cand_stride, c->med + 3 * s0, col0, st));
-    // (3) images with a plane the fast path could not settle: their spectrum after all (the others return at once), then the fallbacks
-    ColParams gt{};
-    gt.gate = sel;
-    { StageMode mg; mg.fwd_plain_extra = &gt;
-      rc = enqueue_fft_stage(c, s0, g, final_fwd, rgb_in, nullptr, st, mg); }
-    if (rc) return rc;
-    HIPCHK(c, launch_stat_settle(c->spec(s0), s.PH, s.PWi, c->slot_stride, g, sel, c->med + 3 * s0, &cap, partial, amb, usable, st));
-    for (int i = 0; i < g; i++) { c->slots[s0 + i].has_spec = false; c->slots[s0 + i].rgb_src = nullptr; }
+    if (phases & 8) {
+        rc = enqueue_tilestats_select(c, s0, g, st);
+        if (rc) return rc;
+    }
+    if (phases & 16) return enqueue_tilestats_tail(c, s0, g, rgb_in, st, cap, usable);
     return TFFT_OK;
 }
 
@@ -1182,11 +1201,31 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         if (p.bw > 0 && p.s_lo <= p.s_hi && p.s_hi < 0xFFFFFFFFull && mirror_d > p.s_hi && !pl.direct && pl.log_n2 >= 4 && pl.log_n2 <= 9 &&
             (unsigned long long)s.PH * s.PWi <= (1ull << 24) && (s.PWi / 2) % 16 == 0) {
             em.em_m2 = 0;
-            rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable);
+            rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable, 7);
+            if (rc) return rc;
+            // the select chain is five small dependent launches: on a side stream beside the inverse transform, which does not wait for it
+            hipStream_t sst = st;
+            if (c->stats_async) {
+                if (!c->stream_stats[which]) {
+                    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_stats[which], hipStreamNonBlocking));
+                    HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_fork[which], hipEventDisableTiming));
+                    HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_join[which], hipEventDisableTiming));
+                }
+                sst = c->stream_stats[which];
+                HIPCHK(c, hipEventRecord(c->ev_stats_fork[which], st));
+                HIPCHK(c, hipStreamWaitEvent(sst, c->ev_stats_fork[which], 0));
+            }
+            rc = enqueue_tilestats_select(c, s0, g, sst);
             if (rc) return rc;
             StageMode mi;
-            mi.inv_embed = &em; mi.inv_cover = rgb_in;
-            return enqueue_inverse(c, s0, g, rgb_out, st, mi);
+            mi.inv_embed = &em; mi.inv_cover = rgb_in; mi.inv_via_spec = true;
+            rc = enqueue_inverse(c, s0, g, rgb_out, st, mi);
+            if (rc) return rc;
+            if (sst != st) {
+                HIPCHK(c, hipEventRecord(c->ev_stats_join[which], sst));
+                HIPCHK(c, hipStreamWaitEvent(st, c->ev_stats_join[which], 0));
+            }
+            return enqueue_tilestats_tail(c, s0, g, rgb_in, st, p, usable);
         }
     }
     StageMode md;

@@ -52,6 +52,7 @@ struct ColParams {
     // values); the packed column 0 goes to st_col0 for k_col0_stats
     struct SelectState* st_sel;      // 3 per image
     unsigned* st_cand; size_t st_cand_stride;
+    unsigned st_resv;           // COLS_STAT: slots of the candidate list each wave of the launch owns (set by the launcher: 64 per tile it walks)
     unsigned st_cand_fixed;     // COLS_STAT: slots at the head of a plane's list owned by the launch's waves (set by the launcher); appended entries follow
     unsigned* st_partial;            // per (image, plane) TFFT_STAT_MAX_BLOCKS counters (a workgroup adds to slot block % that)
     float* st_amb;
@@ -62,6 +63,9 @@ struct ColParams {
     int tile_step, tile_off; int out_M; size_t out_plane_stride, out_img_stride;      // tiles tile_off + i*tile_step
     // forward COLS_PLAIN only: images whose statistics were settled without the spectrum (all three planes) return at once
     const struct SelectState* gate;
+    // forward COLS_PLAIN sample pass: instead of storing the narrow spectrum, every value's |F|^2 goes into a 4096-bucket histogram (the
+    // top 13 bits of the float, weight 2) kept in LDS at byte offset hist_lds_off and added to hist_sel[3*img + plane].hist at the end
+    struct SelectState* hist_sel; unsigned hist_lds_off;
     int em_on;
     // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
     // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off

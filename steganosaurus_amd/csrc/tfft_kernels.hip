@@ -1029,9 +1029,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // 4K bucket (a longer one fetches the rest in place, a dependent round trip in the middle of the tile): first inverse step
     // 0.547 -> 0.512 ms per 8 x 4K launch (round 3, gpurun_out/r3f; round 2's kernel, one workgroup per CU at 247 registers, lost by it)
 #ifndef TFFT_EMBED_NE9
-#ifndef TFFT_STAT_RESV
-#define TFFT_STAT_RESV 192      // slots of the candidate list a wave reserves at a time
-#endif
 #ifndef TFFT_STAT_SLOTS
 #define TFFT_STAT_SLOTS 193     // staged candidates per wave (+ one spare slot), flushed once per tile
 #endif
@@ -1049,6 +1046,10 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
         const unsigned b0 = (unsigned)((plane * P.G + (g < P.G ? g : 0)) * ntiles);
         for (int i = em_tid; i <= NOFF; i += em_nthr) lds_eo[i] = P.rd_off[b0 + (unsigned)imin(tile0 + i, ntiles)];
     }
+    unsigned* lds_hist = reinterpret_cast<unsigned*>(tfft_smem + P.hist_lds_off);
+    const bool hist_on = (MODE == COLS_PLAIN && SIGN > 0 && FULL) && P.hist_sel != nullptr;      // workgroup uniform
+    if (hist_on)
+        for (int i = (gl * T + t) * C + c; i < 4096; i += (int)(blockDim.x * blockDim.y * blockDim.z)) lds_hist[i] = 0;
     lds_barrier();            // the tables above (DC rows, output twiddles, pass twiddles, bucket offsets)
     auto em_range = [&](int tile, unsigned& e0, unsigned& e1) {
         const int i = imin(tile - tile0, NOFF - 1);
@@ -1102,21 +1103,21 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     const unsigned st_span_b = st_base > 0x7F800000u ? 0u : (st_span_raw < 0x7F800000u - st_base ? st_span_raw : 0x7F800000u - st_base);
     const unsigned st_aspan = (MODE == COLS_STAT && P.st_shi >= P.st_slo) ? P.st_shi - P.st_slo : 0u;       // annulus: d1 - s_lo <= st_aspan
     const unsigned st_t2lo_b = __float_as_uint(st_t2lo), st_t2win = __float_as_uint(st_t2hi) - st_t2lo_b;  // threshold window on the bits (values >= 0)
-    // Every wave of the launch owns TFFT_STAT_RESV slots at the head of the plane's candidate list (wave w of workgroup b: slots
-    // (b * nwaves + w) * RESV ..), fills what it does not use with TFFT_CAND_HOLE at the end (the select kernels skip those), and only a
+    // Every wave of the launch owns P.st_resv slots at the head of the plane's candidate list (wave w of workgroup b: slots
+    // (b * nwaves + w) * st_resv ..), fills what it does not use with TFFT_CAND_HOLE at the end (the select kernels skip those), and only a
     // wave with more candidates than that appends the rest behind the fixed part with a global atomic.  (First form: one atomic per
     // flush, whose round trip the wave sat out -- ~0.1 ms of a 1080p batch's 0.68; reserving with one atomic per wave at the start was
     // worse still, 0.99: a thousand waves per plane queue on one address at once.)
-    unsigned* st_region = st_out + (size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6)) + st_wave) * TFFT_STAT_RESV;
+    unsigned* st_region = st_out + (size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6)) + st_wave) * P.st_resv;
     if (MODE == COLS_STAT && blockIdx.x == 0 && blockIdx.y == 0 && st_lin == 0) st_s->cand_fixed = P.st_cand_fixed;
     unsigned st_used = 0;
     auto st_fill = [&]() {              // wave uniform
-        for (unsigned i = st_used + (st_lin & 63); i < (unsigned)TFFT_STAT_RESV; i += 64) st_region[i] = TFFT_CAND_HOLE;
+        for (unsigned i = st_used + (st_lin & 63); i < P.st_resv; i += 64) st_region[i] = TFFT_CAND_HOLE;
     };
     auto st_flush = [&]() {             // wave uniform: the wave's staged candidates go to its slots of the plane's list
         const unsigned lane = st_lin & 63;
         WaveSync::sync();
-        const unsigned room = (unsigned)TFFT_STAT_RESV - st_used, n1 = st_nstaged < room ? st_nstaged : room;
+        const unsigned room = P.st_resv - st_used, n1 = st_nstaged < room ? st_nstaged : room;
         for (unsigned i = lane; i < n1; i += 64) st_region[st_used + i] = st_wbuf[i];
         st_used += n1;
         if (st_nstaged > n1) {            // rare: behind the fixed part, as k_col0_stats appends its own
@@ -1304,6 +1305,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                     st_value(m, (TFFT_STAT_CUT & 16) ? u[m] : v);
                 } else if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
                     if (P.em_m2 == 1) *reinterpret_cast<float*>(mb + m * (stride_out >> 1) + (vo >> 1)) = fmaf(v.x, v.x, v.y * v.y);      // asked for, nothing at all)
+                } else if (MODE == COLS_PLAIN && SIGN > 0 && hist_on) {      // the statistics' sample: a histogram instead of the narrow spectrum
+                    if ((tile * ts + toff) * C + c != 0) atomicAdd(&lds_hist[__float_as_uint(fmaf(v.x, v.x, v.y * v.y)) >> 19], 2u);
                 } else *reinterpret_cast<float2*>(ob + m * stride_out + vo) = v;
             }
         } else if (((tile * ts + toff) * C + c < P.M) && (g < P.G)) {      // (the sample pass: input column tile*ts+toff, output column block tile of a narrow plane)
@@ -1419,6 +1422,14 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
 #pragma unroll
             for (int m = 0; m < E; m++) u[m] = un[m];
             awc = awn;
+        }
+    }
+    if (MODE == COLS_PLAIN && SIGN > 0 && FULL) {
+        if (hist_on) {
+            lds_barrier();
+            unsigned* gh = P.hist_sel[3 * img + plane].hist;
+            for (int i = (gl * T + t) * C + c; i < 4096; i += (int)(blockDim.x * blockDim.y * blockDim.z))
+                if (lds_hist[i]) atomicAdd(&gh[i], lds_hist[i]);
         }
     }
     if (MODE == COLS_STAT) {            // the workgroup's sums: one global atomic each (a per-thread atomic on one address per plane serialises)
@@ -2722,10 +2733,11 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
     if (gpb > P.G) gpb = P.G;
-    if constexpr (!FULL && (LOGL >= 6 || MODE == COLS_STAT) && MODE != COLS_ROWLIMIT) {
-        // every output element exists: the variant whose stores carry no predicate (ROWLIMIT cuts rows by definition)
+    if constexpr (!FULL && (LOGL >= 6 || MODE == COLS_STAT || (MODE == COLS_PLAIN && SIGN > 0 && !TW)) && MODE != COLS_ROWLIMIT) {
+        // every output element exists: the variant whose stores carry no predicate (ROWLIMIT cuts rows by definition; short columns
+        // only for the statistics, whose classification / histogram live in that store loop)
         const int rows_out_max = P.out_a * (L - 1) + P.out_b * (P.G - 1);
-        if (rows_out_max < P.out_rows && P.M % C == 0 && P.G % gpb == 0)
+        if ((LOGL >= 6 || MODE == COLS_STAT || P.hist_sel) && rows_out_max < P.out_rows && P.M % C == 0 && P.G % gpb == 0)
             return launch_cols_t<LOGL, SIGN, MODE, DC, TW, true>(in, out, tw, P, n_planes, s);
         if (MODE == COLS_STAT) return hipErrorInvalidValue;      // the in-register classification lives in the unpredicated store loop only
     }
@@ -2743,18 +2755,25 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
     const size_t nwaves = ((size_t)C * T * gpb + 63) / 64;
     const size_t lds = lds0 + (BUCKETS ? (size_t)gpb * (C * sizeof(float2) + 18 * sizeof(unsigned)) : 0) +
                        (MODE == COLS_STAT ? (nwaves * (TFFT_STAT_SLOTS + 1) + 2) * sizeof(unsigned) : 0);
+    size_t lds_total = lds;
+    if (MODE == COLS_PLAIN && SIGN > 0 && P.hist_sel) {
+        if (!FULL) return hipErrorInvalidValue;      // the histogram lives in the unpredicated store loop only
+        Q.hist_lds_off = (unsigned)((lds + 15) & ~(size_t)15);
+        lds_total = Q.hist_lds_off + 4096 * sizeof(unsigned);
+    }
     dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     if (MODE == COLS_STAT) {
-        const size_t fixed = (size_t)grid.x * grid.y * nwaves * TFFT_STAT_RESV;
+        Q.st_resv = 64u * (unsigned)tpb;        // a wave stages ~45 of a tile's 1024 values (three sixteenth-octave buckets around the median)
+        const size_t fixed = (size_t)grid.x * grid.y * nwaves * Q.st_resv;
         if (fixed + (size_t)P.PH * (P.M + 1) > P.st_cand_stride) return hipErrorInvalidValue;
         Q.st_cand_fixed = (unsigned)fixed;
     }
     auto k = k_fft_cols<LOGL, SIGN, MODE, DC, TW, FULL>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds_total > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, grid, block, lds, s, in, out, tw, Q);
+    hipLaunchKernelGGL(k, grid, block, lds_total, s, in, out, tw, Q);
     return hipGetLastError();
 }
 hipError_t launch_cols(const float2* in, float2* out, const float2* tw_ph, const ColParams& P, int logl, int sign,
@@ -2963,7 +2982,8 @@ hipError_t launch_stat_guess(const float2* mini, int PH, int PW, int Ms, size_t 
     int step = (int)(((long long)PH * Ms) / 65536); if (step < 1) step = 1; if (step > 64) step = 64;       // ~65 k sampled values per plane
     unsigned nbs = (unsigned)((PH + step - 1) / step);
     { unsigned want = (nbs + 3) / 4; if (want < 1) want = 1; nbs = want < 32u ? want : 32u; }
-    hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed, (const float2*)nullptr);
+    if (mini)       // (nullptr: the sample pass has filled the histograms itself, ColParams::hist_sel)
+        hipLaunchKernelGGL(k_hist_spec, dim3(nbs, 3, n_images), dim3(256), 4096 * sizeof(unsigned), s, mini, PH, Ms, mini_img_stride, st, step, 0, col0_packed, (const float2*)nullptr);
     hipLaunchKernelGGL(k_select_guess, dim3(3 * n_images), dim3(256), sel_lds, s, st, cap ? cap->magmin : -1.0, rank);
     return hipGetLastError();
 }
