@@ -1029,6 +1029,9 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // 4K bucket (a longer one fetches the rest in place, a dependent round trip in the middle of the tile): first inverse step
     // 0.547 -> 0.512 ms per 8 x 4K launch (round 3, gpurun_out/r3f; round 2's kernel, one workgroup per CU at 247 registers, lost by it)
 #ifndef TFFT_EMBED_NE9
+#ifndef TFFT_STAT_LDS_LOG
+#define TFFT_STAT_LDS_LOG 9      // columns from this length on are classified from the parked tile, shorter ones in registers
+#endif
 #ifndef TFFT_STAT_SLOTS
 #define TFFT_STAT_SLOTS 193     // staged candidates per wave (+ one spare slot), flushed once per tile
 #endif
@@ -1267,6 +1270,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
 #ifndef TFFT_STAT_CUT
 #define TFFT_STAT_CUT 0      // measurement builds only
 #endif
+        constexpr bool ST_LDS = (LOGL >= TFFT_STAT_LDS_LOG);
         unsigned st_ambflag = 0;
         auto st_value = [&](int m, float2 v) {
 #if TFFT_STAT_CUT & 8
@@ -1302,7 +1306,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                 if (TW) v = cmul(v, lds_wo[t + m * T]);
                 if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[t + m * T], awc));      // last forward step: the rank-1 term comes back
                 if (MODE == COLS_STAT) {        // nothing is stored
-                    st_value(m, (TFFT_STAT_CUT & 16) ? u[m] : v);
+                    if (!ST_LDS) st_value(m, (TFFT_STAT_CUT & 16) ? u[m] : v);
                 } else if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
                     if (P.em_m2 == 1) *reinterpret_cast<float*>(mb + m * (stride_out >> 1) + (vo >> 1)) = fmaf(v.x, v.x, v.y * v.y);      // asked for, nothing at all)
                 } else if (MODE == COLS_PLAIN && SIGN > 0 && hist_on) {      // the statistics' sample: a histogram instead of the narrow spectrum
@@ -1345,6 +1349,17 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
             if (DC && t == 0) lds_aw[c] = awc;
             lds_barrier();
             if (MODE == COLS_STAT) {
+                if (ST_LDS) {
+                    // L = 512: 32 values per thread -- classified in registers beside the transform's own 64 the kernel spills; from the
+                    // parked tile instead, four values in flight
+#pragma unroll 4
+                    for (int m = 0; m < E; m++) {
+                        const int k = t + m * T;
+                        float2 v = lds[lay.idx(k, c)];
+                        if (DC) v = cadd(v, cmul(lds_ah[k], awc));
+                        st_value(m, v);
+                    }
+                }
                 {
                     auto st_again = [&](int m, float& m2, unsigned& row) -> bool {      // value m of this thread once more, from the parked tile; in the annulus?
                         const int k = t + m * T;
