@@ -85,6 +85,12 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
         if stage == "embed":
             return n_bits * (8 + 1 + 1)
         m2 = plan.get("m2", False)      # the spectrum is stored as |F|^2 (4 B per bin): all the statistics read, and nothing else reads it
+        tile = plan.get("tile_stats", False)      # the statistics' full pass runs inside the last forward column step (COLS_STAT): nothing is stored
+        cand = 3 * plane_full // 32               # but the candidate lists: 64 four-byte slots per wave and tile of 1024 values
+        if tile and stage == final_fwd:
+            return 3 * plane_full + cand + n_bits * (8 + 8)
+        if tile and stage == "medians":           # the sample pass (every 8th column tile) + two histogram passes over the candidate lists
+            return 3 * plane_full // 8 + 2 * cand
         if stage == final_fwd and not (plan["fused"] and stage == "cols_fwd_a"):
             rd = (3 * plane_full) if two_step else 3 * plane_h
             if plan.get("no_store", False):      # no capacity asked for (--no-stats): nobody reads the spectrum, nothing is stored
@@ -193,7 +199,13 @@ class Workload:
         self.plan = self.ctx.plan_info(W, H, min(self.slots, n_img))      # which kernels a launch over the chunk takes
         self.plan["delta"] = int(os.environ.get("TFFT_EMBED_DELTA", "1")) != 0      # the bin list is registered below: delta embedding applies
         PHp, PWp = next_pow2(H), max(2, next_pow2(W))
-        self.plan["m2"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0 and PHp * PWp <= (1 << 24))
+        # (tilestats_applies in tfft_capi.hip: two-step column plans of whole tiles, planes up to 2^24 bins; the default annulus stays left of PW/2)
+        self.plan["tile_stats"] = (self.plan["delta"] and stats and int(os.environ.get("TFFT_STATS_TILE", "1")) != 0 and self.plan["two_step"]
+                                   and 4 <= self.plan["log_n2"] <= 9 and PHp * PWp <= (1 << 24) and (PWp // 2) % 16 == 0
+                                   and (min(self.slots, n_img) * PHp * PWp >= (1 << 24) or int(os.environ.get("TFFT_STATS_TILE", "1")) >= 2)
+                                   and all(int(os.environ.get(k, "1")) != 0 for k in ("TFFT_STATS_FUSED", "TFFT_STATS_COMPACT"))
+                                   and int(os.environ.get("TFFT_MEDIAN_FALLBACK", "0")) == 0)
+        self.plan["m2"] = (self.plan["delta"] and stats and not self.plan["tile_stats"] and int(os.environ.get("TFFT_STATS_M2", "1")) != 0 and PHp * PWp <= (1 << 24))
         self.plan["no_store"] = self.plan["delta"] and not stats and int(os.environ.get("TFFT_STATS_M2", "1")) != 0
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.h_index = d_index.cpu().numpy().astype(np.uint32) if self.sort_bins else None

@@ -1072,6 +1072,19 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
 // forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
+// Do the statistics of a batched delta embed run inside the last forward column step (COLS_STAT)?  Two-step column plans with 16 .. 512
+// rows per step and whole column tiles; planes up to 2^24 bins (the compact select); an annulus that stays left of column PW/2
+// (COLS_STAT counts stored bins only: on tall grids, whose annulus reaches the mirror half, the |F|^2 planes serve); launches of at
+// least 2^24 bins -- four 1080p images, one 4K image (TFFT_STATS_TILE=2: any)
+static bool tilestats_applies(const tfft_ctx* c, const Slot& s, const ColPlan& pl, const CapParams& p, int n) {
+    if (!(c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback)) return false;
+    // a small launch is bound by its dependent launches: this form has 12, the planes' 7 (one 1080p image: 0.314 vs 0.283 ms per round trip)
+    if (c->stats_tile < 2 && (unsigned long long)n * s.PH * s.PWi < (1ull << 24)) return false;
+    const unsigned long long mirror_d = (unsigned long long)(p.PW - s.PWi / 2) * (unsigned long long)(p.PW - s.PWi / 2);
+    return p.bw > 0 && p.s_lo <= p.s_hi && p.s_hi < 0xFFFFFFFFull && mirror_d > p.s_hi && !pl.direct && pl.log_n2 >= 4 && pl.log_n2 <= 9 &&
+           (unsigned long long)s.PH * s.PWi <= (1ull << 24) && (s.PWi / 2) % 16 == 0;
+}
+
 // The statistics after COLS_STAT, in two parts so that the first can run beside the inverse transform (embed_chunk):
 //   select: the medians out of the staged candidates (5 small dependent launches, ~75 us of latency for a 32 x 1080p launch)
 //   tail  : images with a plane the fast path could not settle get their spectrum after all -- the plain last forward step, gated (it
@@ -1190,16 +1203,12 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
         // beside the forward transform it gained nothing measurable: 0.03 ms of 3.3.)
         HIPCHK(c, launch_gather_bits(tb.ent, tb.off + nb, bits, ep.frame_hdr, ep.frame_pay, ep.frame_plen, n_bits, ep.limit, g, tb.pb + (size_t)s0 * n_bits, st));
     }
-    if (delta && usable && c->stats_tile && c->stats_fused && c->stats_compact && !c->median_force_fallback) {
+    if (delta && usable) {
         // the statistics' bracket pass inside the last forward column step: neither the spectrum nor |F|^2 is stored (unless a plane's
         // bracket turns out wrong: then the gated plain step produces the spectrum for the fallback kernels)
-        const ColPlan pl = plan_cols(c, s.PH, s.PWi, g);
         CapParams p = cap_params(c, s, rmin, rmax);
         p.magmin = magmin;
-        // (tall grids, whose annulus reaches the mirror half beyond column PW/2, keep the |F|^2 planes: COLS_STAT counts stored bins only)
-        const unsigned long long mirror_d = (unsigned long long)(p.PW - s.PWi / 2) * (unsigned long long)(p.PW - s.PWi / 2);
-        if (p.bw > 0 && p.s_lo <= p.s_hi && p.s_hi < 0xFFFFFFFFull && mirror_d > p.s_hi && !pl.direct && pl.log_n2 >= 4 && pl.log_n2 <= 9 &&
-            (unsigned long long)s.PH * s.PWi <= (1ull << 24) && (s.PWi / 2) % 16 == 0) {
+        if (tilestats_applies(c, s, plan_cols(c, s.PH, s.PWi, g), p, g)) {
             em.em_m2 = 0;
             rc = enqueue_forward_tilestats(c, s0, g, rgb_in, st, em, p, usable, 7);
             if (rc) return rc;
@@ -1696,7 +1705,11 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
     }
     CapParams tcap = cap_params(c, s, 0.05, 0.45);
     tcap.magmin = 0.01;
-    const bool m2 = delta && bits_dev && stats_m2_applies(c, s, tcap);      // the spectrum is stored as |F|^2 + column 0 (see embed_chunk)
+    // the statistics inside the last forward column step (see embed_chunk): that step is timed as COLS_STAT; MEDIANS is everything else
+    // of the statistics -- sample pass + bracket guess before it, select chain, gated step, fallback and capacity kernels after it
+    const bool tile = delta && bits_dev && tilestats_applies(c, s, pl, tcap, n_images) && (stage == final_fwd || stage == MEDIANS);
+    const bool m2 = delta && bits_dev && !tile && stats_m2_applies(c, s, tcap);      // the spectrum is stored as |F|^2 + column 0 (see embed_chunk)
+    if (tile && stage == MEDIANS) launches = 10;
 
     if (n_launches) *n_launches = launches;
     *ms_per_rep = 0.f;
@@ -1717,7 +1730,7 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         }
     }
     ColParams em{};
-    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED) && delta && bits_dev) {
+    if ((stage == COLS_INV_A || stage == final_fwd || stage == EMBED || (stage == MEDIANS && tile)) && delta && bits_dev) {
         if (!index_ok(c, n_bits)) return TFFT_E_STATE;
         const int G = pl.direct ? 1 : (1 << pl.log_n1), ntiles = (s.PWi / 2 + 15) / 16;
         int rc = ensure_buckets(c, 0, n_bits, 3 * ntiles * G, true);
@@ -1728,6 +1741,27 @@ int tfft_profile_stage(tfft_ctx* c, int n_images, int stage, int reps, const voi
         em.rd_bins = c->tb[0].ent; em.rd_off = c->tb[0].off; em.trash = c->trash; em.em_fl = c->tb[0].fl; em.em_pb = c->tb[0].pb; em.em_n = n_bits;
         em.em_cos = ep0.cos_a; em.em_sin = ep0.sin_a;
         if (m2) { em.em_m2 = 1; em.st_col0 = c->col0_pool; }
+    }
+    if (tile) {
+        // phases of enqueue_forward_tilestats: 2 sample + guess, 4 COLS_STAT, 8 select, 16 tail.  The COLS_STAT step alone needs a bracket
+        // (one untimed sample pass); MEDIANS = the whole sequence minus the COLS_STAT launches it contains, timed the same way
+        float ms_all = 0.f, ms_stat = 0.f;
+        int rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 2);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+        for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 4); if (rc) return rc; }
+        HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_t1));
+        HIPCHK(c, hipEventElapsedTime(&ms_stat, c->ev_t0, c->ev_t1));
+        if (stage == MEDIANS) {
+            HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+            for (int r = 0; r < reps; r++) { rc = enqueue_forward_tilestats(c, 0, n_images, (const uint8_t*)rgb_dev, c->stream, em, tcap, c->usable, 2 | 4 | 8 | 16); if (rc) return rc; }
+            HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev_t1));
+            HIPCHK(c, hipEventElapsedTime(&ms_all, c->ev_t0, c->ev_t1));
+        }
+        *ms_per_rep = (stage == MEDIANS ? (ms_all > ms_stat ? ms_all - ms_stat : 0.f) : ms_stat) / (float)reps;
+        return TFFT_OK;
     }
     HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
     for (int r = 0; r < reps; r++) {

@@ -673,7 +673,8 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     # ... TFFT_STATS_M2=0 / TFFT_STATS_ASYNC=0: the statistics on the complex spectrum, in line (the A/B forms of the default)
     # ... TFFT_STATS_TILE=0: the |F|^2 planes + the statistics kernels over them instead of the classification inside the last forward
     # column step (the default since round 3); with the skew the gated fallback of either form runs
-    for env in ({"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_SKEW": "5"},
+    # ... TFFT_STATS_TILE=2: the in-kernel form also for launches of few images (by default from 2^24 bins per launch on)
+    for env in ({"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "2", "TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_SKEW": "5"},
                 {"TFFT_STATS_TILE": "0", "TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}):
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
@@ -732,7 +733,7 @@ def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.
             one.forward_rgb8(imgs[i])
             want[(rmin, rmax, magmin, i)] = one.capacity(magmin * one.medians(), rmin, rmax)
     one.close()
-    for env in ({}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"}):
+    for env in ({}, {"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"}):
         os.environ.update(env)
         try:
             ctx = B.Context(w, h, slots=2, lib=lib)

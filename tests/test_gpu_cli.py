@@ -148,6 +148,9 @@ def test_png_pipeline_files_are_read_by_the_reference(tmp_path):
     files, several chunks deep so that the three stages overlap.  Every file it writes must give its secret back to the REFERENCE CLI
     (stbi_load + do_extract, S:1112-1312), and tfp_extract_png_batch must return the frames' bytes."""
     import ctypes as C
+    import torch
+    assert torch.cuda.is_available()      # torch's HIP runtime first: initialised after ours in the same process it finds no device (the
+    torch.zeros(1, device="cuda")         # parity tests that follow in this pytest run need it)
     from steganosaurus_amd import binding as B
     host = C.CDLL(os.path.join(ROOT, "steganosaurus_amd", "libtfhost.so"))
     host.tfh_frame_bits.restype = C.c_uint64
