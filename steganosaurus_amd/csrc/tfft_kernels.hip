@@ -1089,7 +1089,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
     // (128 slots behind the bucket offsets; flushed with one global atomic once more than 64 are waiting: a value adds at most 64)
     const int st_lin = (gl * T + t) * C + c, st_wave = st_lin >> 6;
     unsigned* st_wbuf = lds_eo + (blockDim.z - gl) * (NOFF + 2) + st_wave * TFFT_STAT_SLOTS;
-    unsigned* st_wcnt = lds_eo + (blockDim.z - gl) * (NOFF + 2) + ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6) * TFFT_STAT_SLOTS;      // [0], [1]: the workgroup's sums, [2 + wave]: a wave's list base
     SelectState* st_s = (MODE == COLS_STAT) ? P.st_sel + 3 * img + plane : nullptr;
     const unsigned st_lo = (MODE == COLS_STAT) ? st_s->lo : 0u, st_span = (MODE == COLS_STAT) ? st_s->hi - st_lo : 0u, st_base = st_lo << 19;
     // (thresholds clamped at 0 -- mag2_threshold answers -inf for "everything passes", |F|^2 is never negative -- so that -1 can stand for
@@ -1448,6 +1447,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
         }
     }
     if (MODE == COLS_STAT) {            // the workgroup's sums: one global atomic each (a per-thread atomic on one address per plane serialises)
+        // (opaque: computed here, not carried through the tile loop in a register the allocator then spills)
+        unsigned* st_wcnt = lds_eo + (blockDim.z - opaque_u32(threadIdx.z)) * (NOFF + 2) + ((blockDim.x * blockDim.y * blockDim.z + 63) >> 6) * TFFT_STAT_SLOTS;      // [0], [1]: the workgroup's sums
         st_fill();
         lds_barrier();
         if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) { st_wcnt[0] = 0; st_wcnt[1] = 0; }
@@ -2435,13 +2436,20 @@ __global__ void k_capacity_final(const unsigned* __restrict__ partial, int nb, u
 // exports for parity tests and the cover hash (S:428-436)
 // ---------------------------------------------------------------------------
 __global__ void k_export_full(const float2* __restrict__ spec, int PH, int PW, int PWout, float2* __restrict__ out) {
-    const size_t n = (size_t)3 * PH * PWout;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n = 3u * (unsigned)PH * (unsigned)PWout;              // <= 3 * 8192 * 8192
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const int x = (int)(e % PWout);
-    const int y = (int)((e / PWout) % PH);
-    const int p = (int)(e / ((size_t)PWout * PH));
-    out[e] = full_bin(spec + (size_t)p * PH * (PW >> 1), y, x, PH, PW);
+    const unsigned r = e / (unsigned)PWout;
+    const int x = (int)(e - r * (unsigned)PWout), p = (int)(r / (unsigned)PH), y = (int)(r - (unsigned)p * (unsigned)PH), M = PW >> 1;
+    const float2* pl = spec + (size_t)p * PH * M;
+    const int ym = (PH - y) & (PH - 1);
+    float2 v;
+    if (x == 0 || x == M) {             // the packed column 0 (unpack_col0)
+        const float2 a = pl[(size_t)y * M], b = pl[(size_t)ym * M];
+        v = x == 0 ? make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y)) : make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+    } else if (x < M) v = pl[(size_t)y * M + x];
+    else v = cconj(pl[(size_t)ym * M + (PW - x)]);
+    out[e] = v;
 }
 // compute_cover_hash's magnitudes (S:428-436) in fp64, straight from the pixels: |F[y][x]| for y, x < region <= 8 is a
 // 3 x region x region corner of the spectrum, i.e. 192 inner products with the image -- no transform needed, and fp64
