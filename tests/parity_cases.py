@@ -674,8 +674,14 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     # ... TFFT_STATS_TILE=0: the |F|^2 planes + the statistics kernels over them instead of the classification inside the last forward
     # column step (the default since round 3); with the skew the gated fallback of either form runs
     # ... TFFT_STATS_TILE=2: the in-kernel form also for launches of few images (by default from 2^24 bins per launch on)
-    for env in ({"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "2", "TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_SKEW": "5"},
-                {"TFFT_STATS_TILE": "0", "TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}):
+    envs = [{"TFFT_STATS_SKEW": "5"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_M2": "0", "TFFT_STATS_ASYNC": "0"}]
+    pi = B.Context(w, h, slots=max(1, nimg - 1), lib=lib)
+    plan = pi.plan_info(w, h, max(1, nimg - 1)); pi.close()
+    if plan["two_step"] and 4 <= plan["log_n2"] <= 9 and (max(2, pw) // 2) % 16 == 0:      # the in-kernel form can serve this geometry
+        envs += [{"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "2", "TFFT_STATS_SKEW": "5"}]
+        if max(1, nimg - 1) * ph * max(2, pw) >= (1 << 24):      # ... and is the default at this launch size: the planes' form as the variant
+            envs += [{"TFFT_STATS_TILE": "0"}, {"TFFT_STATS_TILE": "0", "TFFT_STATS_SKEW": "5"}]
+    for env in envs:
         ctx = _ctx_with_env(env, w, h, slots=max(1, nimg - 1), lib=lib)
         if idx is not None:
             ctx.set_bit_index(idx)
@@ -713,7 +719,8 @@ def check_delta_embedding(lib, orc, bufs, w, h, n_bits, nimg=2, rmax=0.45, cente
     return stats
 
 
-def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0)), flat=False):
+def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0), (0.2, 0.3, 2.5), (0.05, 0.45, 0.0)), flat=False,
+                         envs=({}, {"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"})):
     """Capacity counted inside the medians' full pass (batch path, S:998-1008) == tfft_capacity with thr = magmin * median,
     image by image, exactly: default annulus, an annulus that reaches into the mirror half (rmax > 0.5), thresholds at and
     above the median (thousands of bins inside the threshold's bracket: the parked list overflows and the plain kernel
@@ -733,7 +740,7 @@ def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.
             one.forward_rgb8(imgs[i])
             want[(rmin, rmax, magmin, i)] = one.capacity(magmin * one.medians(), rmin, rmax)
     one.close()
-    for env in ({}, {"TFFT_STATS_TILE": "2"}, {"TFFT_STATS_TILE": "0"}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"}):
+    for env in envs:
         os.environ.update(env)
         try:
             ctx = B.Context(w, h, slots=2, lib=lib)

@@ -376,7 +376,8 @@ def test_stream_batch_two_phase_extract(emu, orc):
 
 
 def test_batch_capacity_inside_the_median_pass(emu):
-    PC.check_batch_capacity(emu, PC.HostBufs, 96, 64, nimg=2)
-    PC.check_batch_capacity(emu, PC.HostBufs, 40, 200, nimg=1, cases=((0.0, 1.5, 0.5),))
+    small = ({}, {"TFFT_MEDIAN_FALLBACK": "1"}, {"TFFT_STATS_FUSED": "0"})      # (direct column plans: the in-kernel statistics never apply)
+    PC.check_batch_capacity(emu, PC.HostBufs, 96, 64, nimg=2, envs=small)
+    PC.check_batch_capacity(emu, PC.HostBufs, 40, 200, nimg=1, cases=((0.0, 1.5, 0.5),), envs=small)
     # fused 2048-wide plan: the statistics inside the last forward column step (COLS_STAT); a flat image among them
-    PC.check_batch_capacity(emu, PC.HostBufs, 2040, 130, nimg=2, cases=((0.05, 0.45, 0.01), (0.05, 0.45, 1.0), (0.05, 0.45, 0.0)), flat=True)
+    PC.check_batch_capacity(emu, PC.HostBufs, 2040, 130, nimg=2, cases=((0.05, 0.45, 0.01), (0.05, 0.45, 1.0)), flat=True, envs=({"TFFT_STATS_TILE": "2"},))
