@@ -55,6 +55,7 @@ struct tfft_ctx {
     float2* spec_pool = nullptr;
     float2* tmp_pool = nullptr;
     unsigned* cand_pool = nullptr;
+    int stats_prio = 1;                   // the statistics' side stream at the lowest stream priority
     int stats_tile = 1;                   // batched delta embeds run the statistics' bracket pass inside the last forward column step and never store
                                           // the spectrum or |F|^2 (TFFT_STATS_TILE=0: |F|^2 planes + the statistics kernels over them, round 2's default)
     int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
@@ -570,6 +571,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_GRAPHS")) c->graph_max_images = atoi(e);
     if (const char* e = getenv("TFFT_EXACT_STATS")) c->exact_stats = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_PRIO")) c->stats_prio = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
@@ -1072,6 +1074,15 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
 
 // one chunk (slots [s0, s0+g), equal geometry) of the two batched pipelines
 // forward transform + statistics of slots [s0, s0+g) without a stored spectrum (see ColParams::st_*): em carries the delta-embedding lists
+// the statistics' side stream: lowest priority, so that its small kernels fill gaps instead of taking workgroup slots from the transform
+// they run beside (TFFT_STATS_PRIO=0: default priority)
+static hipError_t create_stats_stream(tfft_ctx* c, hipStream_t* out) {
+    int lo = 0, hi = 0;
+    if (c->stats_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo);      // numerically greatest = lowest priority
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 // Do the statistics of a batched delta embed run inside the last forward column step (COLS_STAT)?  Two-step column plans with 16 .. 512
 // rows per step and whole column tiles; planes up to 2^24 bins (the compact select); an annulus that stays left of column PW/2
 // (COLS_STAT counts stored bins only: on tall grids, whose annulus reaches the mirror half, the |F|^2 planes serve); launches of at
@@ -1216,7 +1227,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
             hipStream_t sst = st;
             if (c->stats_async) {
                 if (!c->stream_stats[which]) {
-                    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_stats[which], hipStreamNonBlocking));
+                    HIPCHK(c, create_stats_stream(c, &c->stream_stats[which]));
                     HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_fork[which], hipEventDisableTiming));
                     HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_join[which], hipEventDisableTiming));
                 }
@@ -1245,7 +1256,7 @@ static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const 
     const bool async = delta && usable && c->stats_async;
     if (async) {
         if (!c->stream_stats[which]) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->stream_stats[which], hipStreamNonBlocking));
+            HIPCHK(c, create_stats_stream(c, &c->stream_stats[which]));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_fork[which], hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_stats_join[which], hipEventDisableTiming));
         }
