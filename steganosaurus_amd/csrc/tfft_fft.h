@@ -129,11 +129,28 @@ struct LayColumns {   // tile of NB adjacent columns, column index innermost
     int nb;
     __device__ __forceinline__ int idx(int n, int b) const { return n * nb + b; }
 };
+#ifndef TFFT_ROWS_SWZ
+#define TFFT_ROWS_SWZ 1
+#endif
+#if TFFT_ROWS_SWZ
+// Sequences back to back, element n at n ^ ((n >> 4) & 15): an XOR swizzle of the low four bits by the next four.
+//   * the scatter of a radix-16 pass (16 contiguous lanes write elements 16 apart: ds_write_b64 groups of 16 lanes over 32 banks) lands on 16
+//     distinct float2 columns, as the one-pad-slot-per-16 layout it replaces did;
+//   * the gather (32 contiguous lanes read 32 consecutive elements: ds_read_b64 groups of 32 lanes over 64 banks) stays inside one
+//     aligned run of 32 float2 = all 64 banks once.  With the pad slot, lane 31 of every group wrapped onto lane 0's banks and each gather
+//     took two LDS cycles instead of one: SQ_LDS_BANK_CONFLICT was 34-41 % of the LDS cycles of the row and fused kernels (round 3).
+struct LayRows {
+    int pitch;
+    __device__ __forceinline__ int idx(int n, int b) const { return b * pitch + (n ^ ((n >> 4) & 15)); }
+    static constexpr int padded(int n) { return n < 16 ? 16 : n; }
+};
+#else
 struct LayRows {      // sequences back to back, `pitch` float2 apart, one pad slot per 16 elements
     int pitch;
     __device__ __forceinline__ int idx(int n, int b) const { return b * pitch + n + (n >> 4); }
     static constexpr int padded(int n) { return n + (n >> 4) + 1; }
 };
+#endif
 
 // exp(SIGN*2*pi*i*j/N) from a table tw[j] = exp(+2*pi*i*j/N)
 template <int SIGN>
