@@ -58,6 +58,7 @@ struct tfft_ctx {
     int stats_prio = 1;                   // the statistics' side stream at the lowest stream priority
     int stats_tile = 1;                   // batched delta embeds run the statistics' bracket pass inside the last forward column step and never store
                                           // the spectrum or |F|^2 (TFFT_STATS_TILE=0: |F|^2 planes + the statistics kernels over them, round 2's default)
+    int stats_tile_step_forced = 0;
     int stats_tile_step = 8;              // every 8th column tile is the sample (TFFT_STATS_TILE_STEP)
     float2* col0_pool = nullptr;          // [n_slots*3*max_ph] the packed column 0 of batched embeds that store |F|^2 planes (ColParams::st_col0)
     int stats_skew = 0;                   // test hook (TFFT_STATS_SKEW): brackets moved by this many buckets -- the fast path fails, the fallbacks run
@@ -572,7 +573,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_EXACT_STATS")) c->exact_stats = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
     if (const char* e = getenv("TFFT_STATS_PRIO")) c->stats_prio = atoi(e);
-    if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; }
+    if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; c->stats_tile_step_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("TFFT_COLS_TILES_STAT")) c->cols_tiles_stat = atoi(e) > 0 ? atoi(e) : 0;
@@ -1130,7 +1131,11 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     const int final_fwd = pl.direct ? COLS_FWD_A : COLS_FWD_B;
     // the sample: column tiles off, off + step, ..  -- centred in their strides (tiles 0, step, .. sit at the low-frequency end of every
     // stride and read a median several per cent too high: the bracket missed on every padded image)
-    const int M = s.PWi / 2, ntiles = (M + 15) / 16, step = c->stats_tile_step;
+    // eight sampled tiles per plane row group (every 8th of a 2048-wide grid's 64, every 16th of a 4096-wide one's 128): the sample pass is a
+    // chain of dependent tile transforms per workgroup slot, its time goes with the tiles it walks (8 x 4K: 0.117 -> 0.0x ms)
+    const int M = s.PWi / 2, ntiles = (M + 15) / 16;
+    int step = c->stats_tile_step;
+    while (!c->stats_tile_step_forced && ntiles / step > 8) step *= 2;
     const int off = ntiles > step / 2 ? step / 2 : 0;
     const int Ms = 16 * ((ntiles - off + step - 1) / step);
     int rc;

@@ -40,11 +40,12 @@ if b is not None:
 for stage, pat in {
     "rows_fwd": r"k_rowcol_fwd<|k_rows_fwd<",
     "rows_inv": r"k_colrow_inv<|k_rows_inv<",
-    "cols_fwd_a": r"k_fft_cols<\d+, 1, 0, false, true>",                 # first forward column step (output twiddles)
-    "cols_fwd_b": r"k_fft_cols<\d+, 1, [04], (true|false), false>",      # final forward column step (mode 4: it also writes the listed bins' values, delta embedding)
+    # k_fft_cols<LOGL, SIGN, MODE, DC, TW, FULL>
+    "cols_fwd_a": r"k_fft_cols<\d+, 1, 0, false, true, (true|false)>",                 # first forward column step (output twiddles)
+    "cols_fwd_b": r"k_fft_cols<\d+, 1, [45], (true|false), false, (true|false)>|k_fft_cols<\d+, 1, 0, (true|false), false, (true|false)>",      # final forward column step (mode 4 / 5: it also writes the listed bins' values, delta embedding; 5 classifies its values for the statistics; the busiest match wins over the sample pass, mode 0)
     "cols_fwd_read": r"k_fft_cols<\d+, 1, [12], ",                       # the same step as extraction runs it
-    "cols_inv_a": r"k_fft_cols<\d+, -1, [03], (true|false), true>",      # first inverse column step (mode 3: tiles built from the bin lists, delta embedding)
-    "cols_inv_b": r"k_fft_cols<\d+, -1, 0, false, false>",               # last inverse column step (three-pass plans)
+    "cols_inv_a": r"k_fft_cols<\d+, -1, [03], (true|false), true, (true|false)>",      # first inverse column step (mode 3: tiles built from the bin lists, delta embedding)
+    "cols_inv_b": r"k_fft_cols<\d+, -1, 0, false, false, (true|false)>",               # last inverse column step (three-pass plans)
     "embed": r"k_gather_bits$|k_embed$", "read": r"k_read$", "capacity": r"k_capacity<",
 }.items():
     if stage in stages:
@@ -53,8 +54,11 @@ for stage, pat in {
     if b is not None:
         stages[stage] = int(b * 1024)
         kernels[stage] = name
-med = [kib(k) for k in S if k.startswith("k_collect_bracket")] + [kib("k_hist_spec") or 0, kib("k_hist_cand<true>") or 0]
-if med and med[0] is not None:
+med = [kib(k) for k in S if k.startswith("k_collect_bracket")] + [kib(k) or 0 for k in ("k_hist_spec", "k_hist_cand<true>", "k_hist_cand2", "k_col0_stats")]
+if any(re.match(r"k_fft_cols<\d+, 1, 5, ", k) for k in S):      # statistics inside the last forward step: their sample pass is the plain last step over every 8th tile
+    med += [kib(k) or 0 for k in S if re.match(r"k_fft_cols<\d+, 1, 0, (true|false), false, true>", k)]
+med = [m for m in med if m is not None]
+if med:
     stages["medians"] = int(sum(med) * 1024)
 T = json.load(open(out)) if os.path.exists(out) else {}
 T[workload] = stages
