@@ -1295,7 +1295,25 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
             st_capcount += !(x < st_t2hi) ? 1u : 0u;
             st_ambflag = st_ambflag + st_ambflag + ((__float_as_uint(x) - st_t2lo_b < st_t2win) ? 1u : 0u);
         };
-        if (FULL) {
+        if (FULL && MODE == COLS_STAT && !ST_LDS) {
+            // the DC row factors of TFFT_STAT_GROUP values are read together, ahead of those values' staging writes: the compiler cannot
+            // tell the two LDS regions apart, so a read issued per value waited behind the previous value's write and out its own latency
+#ifndef TFFT_STAT_GROUP
+#define TFFT_STAT_GROUP 8
+#endif
+#pragma unroll
+            for (int m0 = 0; m0 < E; m0 += TFFT_STAT_GROUP) {
+                float2 ahv[TFFT_STAT_GROUP];
+#pragma unroll
+                for (int j = 0; j < TFFT_STAT_GROUP; j++) ahv[j] = DC ? lds_ah[t + (m0 + j) * T] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < TFFT_STAT_GROUP; j++) {
+                    float2 v = u[m0 + j];
+                    if (DC) v = cadd(v, cmul(ahv[j], awc));      // the rank-1 term comes back (the same expression as in every other mode)
+                    st_value(m0 + j, v);
+                }
+            }
+        } else if (FULL) {
             char* ob = out_bytes + (size_t)tile * (C * sizeof(float2));
             char* mb = m2_bytes + (size_t)tile * (C * sizeof(float));
             const unsigned vo = opaque_u32(voff_out);
