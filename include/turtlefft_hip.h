@@ -285,7 +285,9 @@ int tfft_bins_sort(tfft_bin* bins, uint32_t* bit_index, uint64_t n);
 /* Optional promise: the n bins at device pointer bins_dev will not change until they are registered again (or with NULL).  The
  * batch extraction calls that are handed exactly this list then keep what they derive from it -- the per-tile buckets of the
  * tile-resident read, the highest row the list touches -- instead of rebuilding it on every call (5 small launches, ~50 us per
- * 32 x 1080p call).  Results are identical either way; tfft_set_bit_index drops what was kept. */
+ * 32 x 1080p call).  Results are identical either way; tfft_set_bit_index drops what was kept.  The batched EMBED calls use the
+ * same cache (their delta form buckets the list too).  It is keyed on address and length: after rewriting the list in place, register
+ * it again.  Bins outside the grid are reported (TFFT_E_BIN_RANGE) by every call on the registered list, not only the first. */
 int tfft_bins_register_dev(tfft_ctx* ctx, const void* bins_dev, uint64_t n);
 int tfft_set_bit_index(tfft_ctx* ctx, const uint32_t* bit_index, uint64_t n);
 

@@ -79,7 +79,7 @@ struct tfft_ctx {
     struct TileBuckets { float2* fl = nullptr; uint8_t* pb = nullptr; uint64_t fl_cap = 0;      /* delta embedding: values of the listed bins, n_slots x n (ColParams::em_fl) */
                          unsigned* cnt = nullptr; unsigned* off = nullptr; TileBin* ent = nullptr; uint64_t cap = 0; int nb_cap = 0;
                          // what the buckets / the last-row scalar currently describe (tfft_bins_register_dev: reused while the registered list is the one passed in)
-                         const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr;
+                         const void* built_for = nullptr; uint64_t built_n = 0; int built_ph = 0, built_pw = 0, built_g = 0; const void* built_index = nullptr; bool built_bad = false;
                          const void* row_for = nullptr; uint64_t row_n = 0; int row_ph = 0, row_pw = 0; } tb[2];
     const void* reg_bins = nullptr; uint64_t reg_n = 0;      // tfft_bins_register_dev
     int embed_delta = 1;                  // batched embeds: stego = cover + IFFT(F' - F) (TFFT_EMBED_DELTA=0: write F' into the spectrum and invert it)
@@ -123,6 +123,9 @@ struct tfft_ctx {
     struct GraphEntry { hipGraphExec_t exec = nullptr; int state = 0; };
     std::map<std::vector<uint64_t>, GraphEntry> graphs;
 #endif
+    int stats_fail_once = 0;              // TFFT_STATS_FAIL_ONCE (test hook)
+    bool stats_dirty = false;             // a statistics launch sequence broke off midway: the select state (histograms left zero by convention) is cleared before the next one
+    bool graphs_stale = false;            // the shared bucket buffers were rebuilt for another list: captured sequences that left the build out must go
     int graph_max_images = 0;             // TFFT_GRAPHS=n: replay calls of up to n images.  Off by default: measured 5 % SLOWER than plain
                                           // launches (0.283 vs 0.267 ms per 1080p round trip) -- a single image is bound by the GPU-side
                                           // latency of its dependent kernels, which a graph does not shorten
@@ -421,7 +424,23 @@ CapParams cap_params(const tfft_ctx* c, const Slot& s, double rmin, double rmax)
 
 // medians of slots [s0, s0+n); cap != nullptr: also their capacities (S:998-1008 with thr = magmin * median) -> usable[0..n)
 // m2: the slots hold |F|^2 planes + packed columns 0 (stats_m2_applies) instead of the spectrum
+// The select kernels leave SelectState.hist zero behind them instead of clearing it in front (one launch less per call): a sequence that
+// breaks off midway -- a failed launch, an error on the side stream -- would hand dirty histograms to every later call on those slots.
+// Whoever sees such a failure marks the context; the next statistics sequence clears the whole state first.
+static int stats_clean_if_dirty(tfft_ctx* c, hipStream_t st) {
+    if (!c->stats_dirty) return TFFT_OK;
+    HIPCHK(c, hipMemsetAsync(c->sel, 0, (size_t)c->n_slots * 3 * sizeof(SelectState), st));
+    c->stats_dirty = false;
+    return TFFT_OK;
+}
+static int enqueue_medians_impl(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap, unsigned long long* usable, bool m2);
 int enqueue_medians(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap = nullptr, unsigned long long* usable = nullptr, bool m2 = false) {
+    int rc = stats_clean_if_dirty(c, st);
+    if (!rc) rc = enqueue_medians_impl(c, s0, n, st, cap, usable, m2);
+    if (rc) c->stats_dirty = true;
+    return rc;
+}
+static int enqueue_medians_impl(tfft_ctx* c, int s0, int n, hipStream_t st, const CapParams* cap, unsigned long long* usable, bool m2) {
     const Slot& s = c->slots[s0];
     // the batch capacity keeps its partial counts and flags in ONE region per call: slots [s0, s0+n) use the start of the pool's
     // share of the compute stream (s0 is 0 or the second half of a two-stream chunk: shares do not overlap for n <= n_slots - s0)
@@ -481,7 +500,7 @@ template <class Enqueue, class After>
 int with_graph(tfft_ctx* c, int n_images, const std::vector<uint64_t>& key, Enqueue&& enqueue, After&& after) {
 #ifndef TFFT_NO_GRAPHS
     if (c->graph_max_images > 0 && n_images > 0 && n_images <= c->graph_max_images && c->n_streams < 2) {
-        if (c->graphs.size() > 64) invalidate_graphs(c);
+        if (c->graphs.size() > 64 || c->graphs_stale) { invalidate_graphs(c); c->graphs_stale = false; }
         auto& e = c->graphs[key];
         if (e.exec) {
             HIPCHK(c, hipGraphLaunch(e.exec, c->stream));
@@ -573,6 +592,7 @@ int tfft_create(int device, int max_w, int max_h, int n_slots, tfft_ctx** out) {
     if (const char* e = getenv("TFFT_EXACT_STATS")) c->exact_stats = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE")) c->stats_tile = atoi(e);
     if (const char* e = getenv("TFFT_STATS_PRIO")) c->stats_prio = atoi(e);
+    if (const char* e = getenv("TFFT_STATS_FAIL_ONCE")) c->stats_fail_once = atoi(e);
     if (const char* e = getenv("TFFT_STATS_TILE_STEP")) { c->stats_tile_step = atoi(e); if (c->stats_tile_step < 8) c->stats_tile_step = 8; c->stats_tile_step_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES")) { c->cols_tiles_per_block = atoi(e) > 0 ? atoi(e) : 1; c->cols_tiles_forced = 1; }
     if (const char* e = getenv("TFFT_COLS_TILES_EMBED")) c->cols_tiles_embed = atoi(e) > 0 ? atoi(e) : 0;
@@ -1067,9 +1087,20 @@ static int build_buckets(tfft_ctx* c, int which, const tfft_bin* bins, uint64_t 
     const bool registered = bins == c->reg_bins && n_bits == c->reg_n;
     if (!(registered && tb.built_for == bins && tb.built_n == n_bits && tb.built_ph == s.PH && tb.built_pw == s.PWi && tb.built_g == G &&
           tb.built_index == c->bit_index)) {
+        // a sequence captured for a registered list holds no bucket build: once the buffers describe another list it must not be replayed
+        if (tb.built_for) c->graphs_stale = true;
         HIPCHK(c, launch_bucket_bins(bins, c->bit_index, n_bits, s.PH, s.PWi, G, tb.cnt, tb.off, tb.ent, c->err, c->tile_read == 2, st));
         tb.built_for = registered ? bins : nullptr; tb.built_n = n_bits; tb.built_ph = s.PH; tb.built_pw = s.PWi; tb.built_g = G; tb.built_index = c->bit_index;
+        tb.built_bad = false;
+        if (registered && st == c->stream) {      // the cached buckets outlive this call: so does the verdict on the list (one sync per registration and geometry)
+            const int rc = check_err_flag(c);
+            if (rc == TFFT_E_BIN_RANGE) tb.built_bad = true;
+            else if (rc) return rc;
+        }
     }
+    // every call on a registered list with bins outside the grid reports them (at its end, as the call that built the buckets does),
+    // not only the first: the flag the builder raised is raised again
+    if (tb.built_bad) HIPCHK(c, hipMemsetAsync(c->err, 0x01, sizeof(int), st));
     return TFFT_OK;
 }
 
@@ -1182,9 +1213,25 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
 }
 
 struct FrameSrc { const uint8_t* hdr; const uint8_t* pay; uint64_t plen; };      // packed frames of a chunk (device), image i at hdr + 38*i / pay + plen*i
+static int embed_chunk_impl(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
+                            uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                            unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit, const FrameSrc* frame);
 static int embed_chunk(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
                        uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
                        unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit = ~0ull, const FrameSrc* frame = nullptr) {
+    int rc = usable ? stats_clean_if_dirty(c, st) : TFFT_OK;
+    if (!rc) rc = embed_chunk_impl(c, s0, g, rgb_in, bins, bits, n_bits, alpha, rmin, rmax, magmin, usable, rgb_out, st, limit, frame);
+    if (!rc && usable && c->stats_fail_once) {      // test hook (TFFT_STATS_FAIL_ONCE): as if the sequence had broken off -- garbage in the select state, an error out
+        c->stats_fail_once = 0;
+        HIPCHK(c, hipMemsetAsync(c->sel, 0x01, (size_t)c->n_slots * 3 * sizeof(SelectState), st));
+        rc = TFFT_E_HIP;
+    }
+    if (rc && usable) c->stats_dirty = true;      // (the statistics may have been cut off between two of their launches)
+    return rc;
+}
+static int embed_chunk_impl(tfft_ctx* c, int s0, int g, const uint8_t* rgb_in, const tfft_bin* bins, const uint8_t* bits,
+                            uint64_t n_bits, double alpha, double rmin, double rmax, double magmin,
+                            unsigned long long* usable, uint8_t* rgb_out, hipStream_t st, uint64_t limit, const FrameSrc* frame) {
     const Slot& s = c->slots[s0];
     if (!index_ok(c, n_bits)) return TFFT_E_STATE;
     EmbedParams ep = embed_params(c, s, n_bits, alpha, 0, nullptr, false);
@@ -1483,6 +1530,7 @@ int tfft_embed_stream_batch_dev(tfft_ctx* c, int n_images, const void* rgb_dev, 
                                 uint64_t n_bins, const void* header_dev, const void* payload_dev, uint64_t payload_len, double alpha,
                                 double rmin, double rmax, double magmin, void* usable_out_dev, void* rgb_out_dev) {
     if (!c || n_images < 0 || !rgb_dev || !rgb_out_dev || !bins_dev || !header_dev || (payload_len && !payload_dev)) return TFFT_E_INVALID;
+    if (n_bins < 912 || payload_len > (n_bins - 912) / 56) return TFFT_E_INVALID;      // (before the multiplication: a huge length must not wrap)
     const uint64_t n_bits = 38ull * 24 + payload_len * 56;           // S:986-995
     if (n_bits > n_bins) return TFFT_E_INVALID;                      // the caller's walk is shorter than the stream
     if (!index_ok(c, n_bins)) return TFFT_E_STATE;
@@ -1659,7 +1707,7 @@ int tfft_embed_stream_batch(tfft_ctx* c, int n_images, const uint8_t* rgb, int w
                             const uint8_t* header, const uint8_t* payload, uint64_t payload_len, double alpha, double rmin, double rmax,
                             double magmin, uint64_t* usable_out, uint8_t* rgb_out) {
     if (!c || n_images < 0 || !rgb || !rgb_out || !bins || !header || (payload_len && !payload) || n_bins == 0) return TFFT_E_INVALID;
-    if (38ull * 24 + payload_len * 56 > n_bins) return TFFT_E_INVALID;
+    if (n_bins < 912 || payload_len > (n_bins - 912) / 56) return TFFT_E_INVALID;      // the walk is shorter than the stream (no wrap for huge lengths)
     StreamIO io; io.header_in = header; io.payload_in = payload; io.plen = payload_len;
     return batch_host(c, true, n_images, rgb, w, h, center, bins, nullptr, n_bins, alpha, rmin, rmax, magmin, usable_out, rgb_out, nullptr, &io);
 }

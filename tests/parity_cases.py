@@ -419,6 +419,14 @@ def check_error_paths(lib):
         raise AssertionError("axis bin must be rejected")
     except B.TfftError as e:
         assert e.status == -8
+    # a payload length whose bit count wraps in 64 bits (38*24 + 56*len == 912 + 56 mod 2^64) must not pass for a short stream
+    dummy = np.zeros(64, np.uint8)
+    for plen in ((1 << 64) // 56 + 2, (1 << 63)):
+        try:
+            ctx.embed_stream_batch_dev(1, dummy.ctypes.data, 64, 64, dummy.ctypes.data, 2000, dummy.ctypes.data, dummy.ctypes.data, plen, dummy.ctypes.data)
+            raise AssertionError("payload length beyond the walk must be rejected")
+        except B.TfftError as e:
+            assert e.status == -1, e.status      # TFFT_E_INVALID
     ctx.close()
     try:
         B.Context(70000, 8, lib=lib)
@@ -755,3 +763,23 @@ def check_batch_capacity(lib, bufs, w, h, nimg=3, cases=((0.05, 0.45, 0.01), (0.
             for i in range(nimg):
                 assert int(got[i]) == want[(rmin, rmax, magmin, i)], (env, rmin, rmax, magmin, i, int(got[i]), want[(rmin, rmax, magmin, i)])
         ctx.close()
+    # a statistics sequence that broke off (test hook: garbage in the select state + an error) must not poison the next call
+    os.environ["TFFT_STATS_FAIL_ONCE"] = "1"
+    try:
+        ctx = B.Context(w, h, slots=2, lib=lib)
+    finally:
+        del os.environ["TFFT_STATS_FAIL_ONCE"]
+    (rmin, rmax, magmin) = cases[0]
+    ui, up = bufs.put(np.full(nimg, -1, np.int64))
+    try:
+        ctx.embed_batch_dev(nimg, ip, w, h, kp, bp, 16, op, rmin=rmin, rmax=rmax, magmin=magmin, usable_ptr=up)
+        raise AssertionError("the injected failure did not surface")
+    except B.TfftError:
+        pass
+    ctx.embed_batch_dev(nimg, ip, w, h, kp, bp, 16, op, rmin=rmin, rmax=rmax, magmin=magmin, usable_ptr=up)
+    ctx.sync()
+    got = bufs.get(ui)
+    for i in range(nimg):
+        assert int(got[i]) == want[(rmin, rmax, magmin, i)], ("after a broken statistics sequence", i, int(got[i]), want[(rmin, rmax, magmin, i)])
+    ctx.close()
+
