@@ -599,6 +599,8 @@ def test_batch_capacity_inside_the_median_pass(lib):
     PC.check_batch_capacity(lib, PC.TorchBufs, 640, 360)
     PC.check_batch_capacity(lib, PC.TorchBufs, 1920, 1080, nimg=2, cases=((0.05, 0.45, 0.01), (0.0, 1.5, 0.3), (0.1, 0.6, 1.0)))
     PC.check_batch_capacity(lib, PC.TorchBufs, 1920, 1080, nimg=2, cases=((0.05, 0.45, 0.01), (0.05, 0.45, 1.0), (0.05, 0.45, 0.0)), flat=True)
+    PC.check_batch_capacity(lib, PC.TorchBufs, 1000, 1000, nimg=2, cases=((0.05, 0.45, 0.01), (0.1, 0.3, 0.5)), flat=True)
+    PC.check_batch_capacity(lib, PC.TorchBufs, 700, 3000, nimg=2, cases=((0.05, 0.45, 0.01),))
     # (4K: no threshold AT the median here -- the single-image call this is held to is exact since round 3, the batch counts on fp32 magnitudes,
     # and of 25 M bins a couple sit within fp32 rounding of their own median)
     PC.check_batch_capacity(lib, PC.TorchBufs, 3840, 2160, nimg=2, cases=((0.05, 0.45, 0.01), (0.1, 0.6, 0.3)))
@@ -714,7 +716,9 @@ def test_wide_fused_batch_equals_forced_single(lib, orc):
 
 
 @pytest.mark.parametrize("case", [dict(w=200, h=120, n_bits=3000), dict(w=300, h=700, n_bits=6000, rmax=0.95), dict(w=2048, h=256, n_bits=20000, center=True),
-                                  dict(w=1920, h=1080, n_bits=n_stream_bits(4096), nimg=2), dict(w=3840, h=2160, n_bits=n_stream_bits(32768), nimg=2, sort=False)])
+                                  dict(w=1920, h=1080, n_bits=n_stream_bits(4096), nimg=2), dict(w=3840, h=2160, n_bits=n_stream_bits(32768), nimg=2, sort=False),
+                                  # unfused two-step column plans with short second steps (32 and 64 rows: COLS_STAT's small instantiations, waves that span two row groups)
+                                  dict(w=1000, h=1000, n_bits=20000, nimg=3), dict(w=700, h=3000, n_bits=20000, nimg=2, with_oracle=False, lsb_frac=1e-3)])
 def test_delta_embedding_against_oracle(lib, orc, case):
     """The batched embed pipeline (stego = cover + IFFT(F' - F), tiles built from the bucketed bins) against the fp64 reference's stego
     image, the write-then-invert pipeline and the reference's reading of our stego image: direct, two-step and both fused plans."""
