@@ -1266,20 +1266,14 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
         // (st_row0 opaque: the rows do not depend on the tile, and left visible the compiler computes every row's square and the
         // axis tests once before the tile loop -- 50 spilled dwords -- instead of two instructions per value inside it)
         const unsigned st_col2 = (unsigned)col * (unsigned)col, st_rstep = (unsigned)(P.out_a * T), st_row0 = opaque_u32((unsigned)(P.out_a * t + P.out_b * g));
-#ifndef TFFT_STAT_CUT
-#define TFFT_STAT_CUT 0      // measurement builds only
-#endif
         constexpr bool ST_LDS = (LOGL >= TFFT_STAT_LDS_LOG);
         unsigned st_ambflag = 0;
         auto st_value = [&](int m, float2 v) {
-#if TFFT_STAT_CUT & 8
-            st_capcount += (v.x > 1e30f) ? 1u : 0u; return;      // measurement build: the value is used, nothing else
-#endif
             const float m2 = st_valid ? fmaf(v.x, v.x, v.y * v.y) : -1.0f;
             const unsigned b = __float_as_uint(m2), rel = b - st_base, row = st_row0 + (unsigned)m * st_rstep;
             // median: values below the bracket are counted, values inside it staged for the select (lanes without one write the spare slot)
             st_below += (b < st_base) ? 1u : 0u;
-            const bool cnd = rel <= st_span_b && !(TFFT_STAT_CUT & 32);
+            const bool cnd = rel <= st_span_b;
             const unsigned long long mk = __ballot(cnd);
             {   // straight-line on purpose: a branch per value ("any candidate in the wave?") keeps the compiler from overlapping the sixteen
                 // values' LDS reads and chains, and the wave sat out each one in turn (round 3: 0.12 ms of a 1080p batch's 0.69)
@@ -1289,7 +1283,6 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
             }
             // capacity (S:998-1008): bins of the annulus at or above the threshold window are counted; a value inside the window only
             // leaves a mark (bit E-1-m of st_ambflag: rare, picked up from the parked tile below)
-            if (TFFT_STAT_CUT & 64) return;
             const unsigned d1 = __umul24(row, row) + st_col2;           // rows < 2^13
             const float x = (d1 - P.st_slo <= st_aspan) ? m2 : -1.0f;
             st_capcount += !(x < st_t2hi) ? 1u : 0u;
@@ -1322,8 +1315,7 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                 float2 v = u[m];
                 if (TW) v = cmul(v, lds_wo[t + m * T]);
                 if (DC && SIGN > 0) v = cadd(v, cmul(lds_ah[t + m * T], awc));      // last forward step: the rank-1 term comes back
-                if (MODE == COLS_STAT) {        // nothing is stored
-                    if (!ST_LDS) st_value(m, (TFFT_STAT_CUT & 16) ? u[m] : v);
+                if (MODE == COLS_STAT) {        // nothing is stored (L = 512: the values are classified from the parked tile below; shorter columns: above)
                 } else if (MODE == COLS_EMIT && P.em_m2) {      // nothing but the statistics will read this: |F|^2, half the bytes (2: no statistics
                     if (P.em_m2 == 1) *reinterpret_cast<float*>(mb + m * (stride_out >> 1) + (vo >> 1)) = fmaf(v.x, v.x, v.y * v.y);      // asked for, nothing at all)
                 } else if (MODE == COLS_PLAIN && SIGN > 0 && hist_on) {      // the statistics' sample: a histogram instead of the narrow spectrum
