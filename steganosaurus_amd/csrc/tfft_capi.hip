@@ -226,7 +226,7 @@ static void copy_embed_fields(ColParams& cp, const ColParams& e) {
 static void copy_plain_extra(ColParams& cp, const ColParams& e) {
     if (e.tile_step > 1) cp.tiles_per_block = e.hist_sel ? 2 : 1;      // the sample: an eighth of the tiles; few per workgroup keep the grid wide
     cp.tile_step = e.tile_step; cp.tile_off = e.tile_off; cp.out_M = e.out_M; cp.out_plane_stride = e.out_plane_stride; cp.out_img_stride = e.out_img_stride; cp.gate = e.gate;
-    cp.hist_sel = e.hist_sel;
+    cp.hist_sel = e.hist_sel; cp.g_step = e.g_step; cp.g_off = e.g_off;
 }
 
 // How a launch sequence wants the outer column steps and the inverse row kernel to run: handed down explicitly per call (until round 3
@@ -1167,6 +1167,11 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     const int M = s.PWi / 2, ntiles = (M + 15) / 16;
     int step = c->stats_tile_step;
     while (!c->stats_tile_step_forced && ntiles / step > 8) step *= 2;
+    // ... and of those tiles every 4th row group only, twice the tiles instead: a sixteenth of the plane rather than an eighth, spread over twice
+    // the columns (the rows of a group are G apart: a regular subsample)
+    const int G = 1 << pl.log_n1;
+    int g_step = 1;
+    if (!c->stats_tile_step_forced && G >= 8 && step >= 2 && ntiles / step >= 2) { g_step = 4; step /= 2; }
     const int off = ntiles > step / 2 ? step / 2 : 0;
     const int Ms = 16 * ((ntiles - off + step - 1) / step);
     int rc;
@@ -1185,7 +1190,7 @@ static int enqueue_forward_tilestats(tfft_ctx* c, int s0, int g, const uint8_t* 
     // 32 x 1080p launch where this takes 0.0x.)
     ColParams ex{};
     ex.tile_step = step; ex.tile_off = off; ex.out_M = Ms; ex.out_plane_stride = (size_t)s.PH * Ms; ex.out_img_stride = (size_t)3 * s.PH * Ms;
-    ex.hist_sel = sel;
+    ex.hist_sel = sel; ex.g_step = g_step; ex.g_off = g_step / 2;
     if (phases & 2) {
         StageMode ms;
         ms.fwd_plain_extra = &ex;

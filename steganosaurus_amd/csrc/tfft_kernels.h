@@ -66,6 +66,7 @@ struct ColParams {
     // forward COLS_PLAIN sample pass: instead of storing the narrow spectrum, every value's |F|^2 goes into a 4096-bucket histogram (the
     // top 13 bits of the float, weight 2) kept in LDS at byte offset hist_lds_off and added to hist_sel[3*img + plane].hist at the end
     struct SelectState* hist_sel; unsigned hist_lds_off;
+    int g_step, g_off;          // ... and only the row groups g_off + i*g_step of the launch (0: all): rows g + G*k, a regular subsample of the rows
     int em_on;
     // DC removal (forward, final step only): out[row][col] += dc_ah[row] * dc_aw[col] -- the transform of the constant that
     // the row kernels subtracted from the pixels, c*A_H(y)*A_W(x); nullptr = off

@@ -907,7 +907,8 @@ __global__ void __launch_bounds__(cols_threads(LOGL)) TFFT_WAVES_PER_EU((MODE ==
                            ColParams P) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
     const int c = threadIdx.x, t = threadIdx.y, gl = threadIdx.z;
-    const int g = blockIdx.y * blockDim.z + gl;
+    const int g = (MODE == COLS_PLAIN && SIGN > 0 && FULL && P.g_step > 1) ? (int)(blockIdx.y * blockDim.z + gl) * P.g_step + P.g_off      // the statistics' sample
+                                                                            : (int)(blockIdx.y * blockDim.z + gl);
     const int img = blockIdx.z / 3, plane = blockIdx.z - 3 * img;      // grid.z = 3 * n_images
     const size_t plane_off = (size_t)img * P.img_stride + (size_t)plane * P.plane_stride;
     float2* lds = reinterpret_cast<float2*>(tfft_smem) + (size_t)gl * L * C;
@@ -2763,14 +2764,17 @@ template <int LOGL, int SIGN, int MODE = COLS_PLAIN, bool DC = false, bool TW = 
 static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw, const ColParams& P, int n_planes,
                                 hipStream_t s) {
     constexpr int L = 1 << LOGL, E = elems_for(L), T = L / E, C = 16;
+    // (the statistics' sample pass may walk every g_step-th row group only)
+    const bool gsample = (MODE == COLS_PLAIN && SIGN > 0 && P.hist_sel && P.g_step > 1);
+    const int Geff = gsample ? (P.G - P.g_off + P.g_step - 1) / P.g_step : P.G;
     int gpb = 256 / (T * C);
     if (gpb < 1) gpb = 1;
-    if (gpb > P.G) gpb = P.G;
+    if (gpb > Geff) gpb = Geff;
     if constexpr (!FULL && (LOGL >= 6 || MODE == COLS_STAT || (MODE == COLS_PLAIN && SIGN > 0 && !TW)) && MODE != COLS_ROWLIMIT) {
         // every output element exists: the variant whose stores carry no predicate (ROWLIMIT cuts rows by definition; short columns
         // only for the statistics, whose classification / histogram live in that store loop)
         const int rows_out_max = P.out_a * (L - 1) + P.out_b * (P.G - 1);
-        if ((LOGL >= 6 || MODE == COLS_STAT || P.hist_sel) && rows_out_max < P.out_rows && P.M % C == 0 && P.G % gpb == 0)
+        if ((LOGL >= 6 || MODE == COLS_STAT || P.hist_sel) && rows_out_max < P.out_rows && P.M % C == 0 && Geff % gpb == 0)
             return launch_cols_t<LOGL, SIGN, MODE, DC, TW, true>(in, out, tw, P, n_planes, s);
         if (MODE == COLS_STAT) return hipErrorInvalidValue;      // the in-register classification lives in the unpredicated store loop only
     }
@@ -2794,7 +2798,8 @@ static hipError_t launch_cols_t(const float2* in, float2* out, const float2* tw,
         Q.hist_lds_off = (unsigned)((lds + 15) & ~(size_t)15);
         lds_total = Q.hist_lds_off + 4096 * sizeof(unsigned);
     }
-    dim3 grid((ntiles + tpb - 1) / tpb, (P.G + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
+    if (gsample && (!FULL || P.g_off + (Geff - 1) * P.g_step >= P.G)) return hipErrorInvalidValue;
+    dim3 grid((ntiles + tpb - 1) / tpb, (Geff + gpb - 1) / gpb, n_planes), block(C, T, gpb);      // n_planes = 3 * n_images
     if (MODE == COLS_STAT) {
         Q.st_resv = 64u * (unsigned)tpb;        // a wave stages ~45 of a tile's 1024 values (three sixteenth-octave buckets around the median)
         const size_t fixed = (size_t)grid.x * grid.y * nwaves * Q.st_resv;
