@@ -89,8 +89,8 @@ def kernel_bytes(stage, w, h, n_bits, n_bins, plan):
         cand = 3 * plane_full // 32               # but the candidate lists: 64 four-byte slots per wave and tile of 1024 values
         if tile and stage == final_fwd:
             return 3 * plane_full + cand + n_bits * (8 + 8)
-        if tile and stage == "medians":           # the sample pass (every 8th column tile) + two histogram passes over the candidate lists
-            return 3 * plane_full // 8 + 2 * cand
+        if tile and stage == "medians":           # the sample pass (a sixteenth of the plane) + two histogram passes over the candidate lists
+            return 3 * plane_full // 16 + 2 * cand
         if stage == final_fwd and not (plan["fused"] and stage == "cols_fwd_a"):
             rd = (3 * plane_full) if two_step else 3 * plane_h
             if plan.get("no_store", False):      # no capacity asked for (--no-stats): nobody reads the spectrum, nothing is stored
